@@ -1,0 +1,148 @@
+"""ctypes binding of libgprx.so (include/gprx.h).  The only way the package reaches the GPU.
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised (``GprxLibraryError`` / the mapped Python exception), never a silent numpy path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libgprx.so"
+
+GPRX_OK, GPRX_EINVAL, GPRX_ENOTPD, GPRX_EHIP, GPRX_ENOMEM, GPRX_ESTATE = range(6)
+TRAIN_VARIANCE, TRAIN_LENGTHSCALE, TRAIN_NOISE, TRAIN_Z = 1, 2, 4, 8
+GEMM_C_LOWER, GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER = 1, 2, 4, 8, 16
+
+KERNEL_IDS = {"RBF": 0, "Matern12": 1, "Matern32": 2, "Matern52": 3, "Exponential": 4}
+
+
+class GprxLibraryError(RuntimeError):
+    """libgprx.so is missing or unusable."""
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/gprx.h
+PROTOTYPES = {
+    "gprx_version": (C.c_int, []),
+    "gprx_last_error": (C.c_char_p, [_vp]),
+    "gprx_device_count": (C.c_int, [_ip]),
+    "gprx_create": (C.c_int, [C.c_int, _i64, C.c_int, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "gprx_destroy": (C.c_int, [_vp]),
+    "gprx_set_stream": (C.c_int, [_vp, _vp]),
+    "gprx_synchronize": (C.c_int, [_vp]),
+    "gprx_set_data": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "gprx_objective": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dp, _vp]),
+    "gprx_factorize": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "gprx_predict": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
+    "gprx_predict_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
+    "gprx_last_timings": (C.c_int, [_vp, _dp]),
+    "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "gprx_dev_malloc": (C.c_int, [C.c_int, _i64, C.POINTER(_vp)]),
+    "gprx_dev_free": (C.c_int, [C.c_int, _vp]),
+    "gprx_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, _i64]),
+    "gprx_memcpy_d2h": (C.c_int, [C.c_int, _vp, _vp, _i64]),
+    "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),
+    "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),
+    "gprx_potrf": (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _ip]),
+    "gprx_mfma_f64_peak": (C.c_int, [C.c_int, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgprx.so once and attach prototypes.  Raises GprxLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise GprxLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  gpras_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise GprxLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise GprxLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error(handle=None) -> str:
+    msg = load().gprx_last_error(handle)
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, handle=None) -> None:
+    """Map a gprx status to the exception the reference's caller would have seen."""
+    if rc == GPRX_OK:
+        return
+    msg = last_error(handle)
+    if rc == GPRX_EINVAL:
+        raise ValueError(msg)
+    if rc == GPRX_ENOTPD:
+        raise np.linalg.LinAlgError(msg)  # tensorflow raises InvalidArgumentError from Cholesky here
+    if rc == GPRX_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"libgprx error {rc}: {msg}")
+
+
+def as_f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(_vp)
+
+
+class DeviceBuffer:
+    """Owning wrapper of a device allocation made through gprx_dev_malloc."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = _vp()
+        check(load().gprx_dev_malloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_array(cls, a, device: int = 0) -> "DeviceBuffer":
+        a = as_f64(a)
+        buf = cls(a.nbytes, device)
+        check(load().gprx_memcpy_h2d(device, buf.ptr, ptr(a), a.nbytes))
+        return buf
+
+    def to_array(self, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.float64)
+        assert out.nbytes <= self.nbytes
+        check(load().gprx_memcpy_d2h(self.device, ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def at(self, offset_elems: int):
+        return _vp(self.ptr.value + 8 * int(offset_elems))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            load().gprx_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,255 @@
+// fp64 MFMA GEMM for gfx950 (v_mfma_f64_16x16x4_f64), row-major operands.
+//
+//   C[M x N] = alpha * op(A) * op(B) + beta * C
+//
+// Used for: the Cholesky trailing update (syrk: A = B = panel, C_LOWER), triangular solves
+// with matrix right-hand sides (updates + products with inverted diagonal blocks), A A^T of
+// the sparse model, K^-1 = L^-T L^-1, and the W P product of the SGPR gradient.
+//
+// Work decomposition (wave64): a workgroup of 4 waves (2 x 2) owns a BM x BN tile of C; each
+// wave owns (BM/2) x (BN/2) = TM x TN MFMA tiles of 16 x 16.  The K loop advances 16 at a
+// time through a double-buffered LDS stage (register prefetch of the next stage, one barrier
+// per stage).  Operands are staged in the orientation they have in memory, so global loads
+// are 16-byte and coalesced along the contiguous dimension for every transpose case:
+//   "KC" image  [rows][16 + 2]   when k is the contiguous dimension (A as stored M x K, B as N x K)
+//   "MC" image  [16][rows + 4]   when m/n is contiguous            (A stored K x M, B stored K x N)
+// MFMA operand lane map (f64 16x16x4): lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; within a 16-deep stage lane group g = l >> 4 takes k = 4g + j for
+// the j-th MFMA (the sum over k is order-free as long as A and B agree), so a KC image is read
+// with two ds_read_b128 per 16-row fragment.  C/D: col = l & 15, row = (l >> 4) + 4 * reg.
+#pragma once
+#include "gprx_common.h"
+
+namespace gprx {
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  double alpha, beta;
+  int flags;
+  int tiles_n;
+};
+
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_LDK = GEMM_BK + 2;  // KC image row stride (doubles): 144 B, 16-B aligned
+
+template <int BMN>
+struct McStride {
+  static constexpr int value = BMN + 4;  // (4 * stride) mod 32 == 16: the two k-rows of a half-wave hit disjoint banks
+};
+
+// ---- global -> registers -----------------------------------------------------------------
+// KC source: rows = tile rows (m or n), 16 contiguous k per row = 8 chunks of 16 B.
+template <int ROWS>
+__device__ __forceinline__ void load_kc(d2 (&r)[ROWS / 32], const double* __restrict__ base, int64_t ld, int row0, int nrows_valid,
+                                        int k0, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q >> 3, cc = q & 7;
+    if (row0 + row < nrows_valid)
+      r[i] = *reinterpret_cast<const d2*>(base + (int64_t)(row0 + row) * ld + k0 + cc * 2);
+    else
+      r[i] = d2{0.0, 0.0};
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_kc(double* s, const d2 (&r)[ROWS / 32], int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q >> 3, cc = q & 7;
+    *reinterpret_cast<d2*>(s + row * GEMM_LDK + cc * 2) = r[i];
+  }
+}
+// MC source: 16 k-rows, each with COLS contiguous m/n values = COLS/2 chunks of 16 B.
+template <int COLS>
+__device__ __forceinline__ void load_mc(d2 (&r)[COLS / 32], const double* __restrict__ base, int64_t ld, int col0, int ncols_valid,
+                                        int k0, int tid) {
+#pragma unroll
+  for (int i = 0; i < COLS / 32; ++i) {
+    const int q = tid + 256 * i;
+    const int krow = q / (COLS / 2), cc = q % (COLS / 2);
+    const int col = col0 + cc * 2;
+    if (col + 1 < ncols_valid) {
+      r[i] = *reinterpret_cast<const d2*>(base + (int64_t)(k0 + krow) * ld + col);
+    } else if (col < ncols_valid) {
+      r[i] = d2{base[(int64_t)(k0 + krow) * ld + col], 0.0};
+    } else {
+      r[i] = d2{0.0, 0.0};
+    }
+  }
+}
+template <int COLS>
+__device__ __forceinline__ void store_mc(double* s, const d2 (&r)[COLS / 32], int tid) {
+#pragma unroll
+  for (int i = 0; i < COLS / 32; ++i) {
+    const int q = tid + 256 * i;
+    const int krow = q / (COLS / 2), cc = q % (COLS / 2);
+    *reinterpret_cast<d2*>(s + krow * McStride<COLS>::value + cc * 2) = r[i];
+  }
+}
+
+// ---- the kernel ----------------------------------------------------------------------------
+// TA == 0: A stored M x K (KC image);  TA == 1: A stored K x M (MC image), op(A) = A^T.
+// TB == 1: B stored N x K (KC image), op(B) = B^T;  TB == 0: B stored K x N (MC image).
+template <int TA, int TB, int BM, int BN>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_kernel(GemmArgs p) {
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
+  constexpr int B_ELEMS = TB ? BN * GEMM_LDK : GEMM_BK * McStride<BN>::value;
+  __shared__ __attribute__((aligned(16))) double smem[2 * (A_ELEMS + B_ELEMS)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, r = lane & 15;
+
+  const int ti = blockIdx.x / p.tiles_n;
+  const int tj = blockIdx.x % p.tiles_n;
+  const int m0 = ti * BM, n0 = tj * BN;
+  if ((p.flags & GEMM_C_LOWER) && n0 > m0 + BM - 1) return;
+
+  int kbeg = 0, kend = p.K;
+  if (p.flags & GEMM_A_LOWER) kend = min(kend, m0 + BM);
+  if (p.flags & GEMM_A_UPPER) kbeg = max(kbeg, m0);
+  if (p.flags & GEMM_B_LOWER) kbeg = max(kbeg, n0);
+  if (p.flags & GEMM_B_UPPER) kend = min(kend, n0 + BN);
+  kbeg &= ~(GEMM_BK - 1);
+  kend = (kend + GEMM_BK - 1) & ~(GEMM_BK - 1);
+  if (kend > p.K) kend = p.K;
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 ra[BM / 32], rb[BN / 32];
+  auto gload = [&](int k0) {
+    if constexpr (TA == 0)
+      load_kc<BM>(ra, p.A, p.lda, m0, p.M, k0, tid);
+    else
+      load_mc<BM>(ra, p.A, p.lda, m0, p.M, k0, tid);
+    if constexpr (TB == 1)
+      load_kc<BN>(rb, p.B, p.ldb, n0, p.N, k0, tid);
+    else
+      load_mc<BN>(rb, p.B, p.ldb, n0, p.N, k0, tid);
+  };
+  auto sstore = [&](int buf) {
+    double* sa = smem + buf * (A_ELEMS + B_ELEMS);
+    double* sb = sa + A_ELEMS;
+    if constexpr (TA == 0)
+      store_kc<BM>(sa, ra, tid);
+    else
+      store_mc<BM>(sa, ra, tid);
+    if constexpr (TB == 1)
+      store_kc<BN>(sb, rb, tid);
+    else
+      store_mc<BN>(sb, rb, tid);
+  };
+
+  if (kbeg < kend) {
+    gload(kbeg);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+      const bool more = (k0 + GEMM_BK) < kend;
+      if (more) gload(k0 + GEMM_BK);
+      const double* sa = smem + buf * (A_ELEMS + B_ELEMS);
+      const double* sb = sa + A_ELEMS;
+      double fa[TM][4], fb[TN][4];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int row = wm * (BM / 2) + a * 16 + r;
+        if constexpr (TA == 0) {
+          const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 4 * g);
+          const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 4 * g + 2);
+          fa[a][0] = lo.x; fa[a][1] = lo.y; fa[a][2] = hi.x; fa[a][3] = hi.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[a][j] = sa[(4 * g + j) * McStride<BM>::value + row];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = wn * (BN / 2) + b * 16 + r;
+        if constexpr (TB == 1) {
+          const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 4 * g);
+          const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 4 * g + 2);
+          fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[b][j] = sb[(4 * g + j) * McStride<BN>::value + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+      if (more) sstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // epilogue: lane holds rows g + 4q (q = 0..3) of column r of each 16 x 16 tile
+  const double alpha = p.alpha, beta = p.beta;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn * (BN / 2) + b * 16 + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * (BM / 2) + a * 16 + g + 4 * q;
+        if (row < p.M && col < p.N) {
+          double* cp = p.C + (int64_t)row * p.ldc + col;
+          double v = alpha * acc[a][b][q];
+          if (beta != 0.0) v += beta * (*cp);
+          *cp = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TA, int TB, int BM, int BN>
+inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p) {
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  if (tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// tile: 0 = choose, 128 or 64 (square workgroup tiles)
+inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
+                              const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0) {
+  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0};
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (tile == 0) {
+    // fill the 256 CUs: 128 x 128 tiles only when there are plenty of them
+    const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_C_LOWER) ? 2 : 1);
+    tile = (t128 >= 384) ? 128 : 64;
+  }
+#define GPRX_GEMM_CASE(TA_, TB_)                                                  \
+  if (ta == TA_ && tb == TB_) {                                                   \
+    if (tile == 128) return launch_gemm_t<TA_, TB_, 128, 128>(st, p);             \
+    return launch_gemm_t<TA_, TB_, 64, 64>(st, p);                                \
+  }
+  GPRX_GEMM_CASE(0, 1)
+  GPRX_GEMM_CASE(0, 0)
+  GPRX_GEMM_CASE(1, 0)
+#undef GPRX_GEMM_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gprx

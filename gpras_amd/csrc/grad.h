@@ -1,0 +1,172 @@
+// Gradient reductions: traces of W against dK/dtheta with the kernel derivative recomputed from
+// the inputs on the fly (nothing of size N x N x n_theta is ever stored).
+//
+// Exact GP:  dLML/dtheta = 1/2 sum_ij W_ij dK_ij/dtheta,  W = alpha alpha^T - K^-1  (lower tiles
+// of K^-1 are read once: 8 N^2 / 2 bytes for all 2 + n_len traces together).
+// Sparse GP: the same contraction with W = dELBO/dKuf (M x N) or dELBO/dKuu (M x M) and, in
+// addition, the row-wise contraction that gives dELBO/dZ.
+//
+// For a stationary kernel K = v g(r2), r2 = sum_k ds_k^2, ds_k = (a_k - b_k) / l_k:
+//   dK/dv = g,   dK/dl_k = -v h ds_k^2 / l_k,   dK/da_k = v h ds_k / l_k,   h = 2 dg/dr2.
+#pragma once
+#include "gprx_common.h"
+#include "kmat.h"
+
+namespace gprx {
+
+struct TraceArgs {
+  const double* a;       // (n1, d) row points (exact: X; sparse: Z)
+  const double* b;       // (n2, d) column points
+  const double* inv_ls;  // d
+  const double* W;       // weights, row-major, ldw
+  int64_t ldw;
+  const double* alpha;   // exact mode: W_ij = alpha_i alpha_j - W[i][j]; else null
+  int n1, n2, d;
+  double variance;
+  int sym;               // 1: a == b, only tiles on/below the diagonal are visited, off-diagonal weights doubled
+  double* partial;       // [grid][2 + d]: S_g, S_trace, S_len[k]
+  int tiles_n;
+};
+
+// One workgroup per 64 x 64 tile.  Thread mapping as kmat_kernel: 8 rows x 2 columns per thread.
+// Output per workgroup (deterministic two-stage reduction, no atomics):
+//   partial[wg][0] = sum w g          partial[wg][1] = sum_{i == j} w      partial[wg][2 + k] = -sum w v h ds_k^2 / l_k
+template <int KID>
+__global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
+  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  __shared__ double sRed[4][KM_DC + 2];
+  const int ti = blockIdx.x / p.tiles_n, tj = blockIdx.x % p.tiles_n;
+  double* out = p.partial + (int64_t)blockIdx.x * (2 + p.d);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.sym && tj > ti) {
+    for (int e = tid; e < 2 + p.d; e += 256) out[e] = 0.0;
+    return;
+  }
+  const int i0 = ti * KM_T, j0 = tj * KM_T;
+  const int cp = lane & 31, rsub = lane >> 5;
+
+  auto stage = [&](int k0) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int q = tid + 256 * rep;
+      const int pt = q >> 3, kk = q & 7;
+      const int k = k0 + kk;
+      double va = 0.0, vb = 0.0;
+      if (k < p.d) {
+        const double s = p.inv_ls[k];
+        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] * s;
+        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] * s;
+      }
+      sA[pt][kk] = va;
+      sBt[kk][pt] = vb;
+    }
+  };
+
+  // pass 1: r2
+  double r2[8][2];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) r2[it][0] = r2[it][1] = 0.0;
+  for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
+    stage(k0);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KM_DC; ++kk) {
+      const d2 bv = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const double av = sA[wave * 16 + 2 * it + rsub][kk];
+        const double d0 = av - bv.x, d1 = av - bv.y;
+        r2[it][0] = __builtin_fma(d0, d0, r2[it][0]);
+        r2[it][1] = __builtin_fma(d1, d1, r2[it][1]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // weights and correlation terms
+  double wh[8][2];  // w * v * h
+  double sg = 0.0, str = 0.0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = i0 + wave * 16 + 2 * it + rsub;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = j0 + 2 * cp + c;
+      double w = 0.0;
+      if (i < p.n1 && j < p.n2) {
+        w = p.W[(int64_t)i * p.ldw + j];
+        if (p.alpha) w = p.alpha[i] * p.alpha[j] - w;
+        if (p.sym) {
+          if (j > i) w = 0.0;
+          else if (j < i) w *= 2.0;
+        }
+      }
+      double g, h;
+      corr_gh<KID>(r2[it][c], g, h);
+      sg = __builtin_fma(w, g, sg);
+      if (i == j) str += w;
+      wh[it][c] = w * p.variance * h;
+    }
+  }
+
+  auto block_sum_store = [&](double v, int slot) {
+    v = wave_sum(v);
+    if (lane == 0) sRed[wave][slot] = v;
+  };
+  block_sum_store(sg, 0);
+  block_sum_store(str, 1);
+  __syncthreads();
+  if (tid < 2) out[tid] = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
+  __syncthreads();
+
+  // pass 2: per-dimension sums  -sum wh ds_k^2 / l_k
+  for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
+    stage(k0);
+    __syncthreads();
+    double sk[KM_DC];
+#pragma unroll
+    for (int kk = 0; kk < KM_DC; ++kk) {
+      const d2 bv = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
+      double acc = 0.0;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const double av = sA[wave * 16 + 2 * it + rsub][kk];
+        const double d0 = av - bv.x, d1 = av - bv.y;
+        acc = __builtin_fma(wh[it][0] * d0, d0, acc);
+        acc = __builtin_fma(wh[it][1] * d1, d1, acc);
+      }
+      sk[kk] = acc;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KM_DC; ++kk) block_sum_store(sk[kk], 2 + kk);
+    __syncthreads();
+    if (tid < KM_DC && k0 + tid < p.d)
+      out[2 + k0 + tid] = -(sRed[0][2 + tid] + sRed[1][2 + tid] + sRed[2][2 + tid] + sRed[3][2 + tid]) * p.inv_ls[k0 + tid];
+    __syncthreads();
+  }
+}
+
+// out[e] = sum over workgroups of partial[wg][e]
+__global__ __launch_bounds__(64) void trace_final(const double* __restrict__ partial, int nwg, int width, double* __restrict__ out) {
+  const int e = blockIdx.x;
+  double s = 0.0;
+  for (int w = threadIdx.x; w < nwg; w += 64) s += partial[(int64_t)w * width + e];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[e] = s;
+}
+
+inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid) {
+  dim3 g(grid), b(256);
+  switch (kid) {
+    case 0: hipLaunchKernelGGL(trace_kernel<0>, g, b, 0, st, p); break;
+    case 1: hipLaunchKernelGGL(trace_kernel<1>, g, b, 0, st, p); break;
+    case 2: hipLaunchKernelGGL(trace_kernel<2>, g, b, 0, st, p); break;
+    case 3: hipLaunchKernelGGL(trace_kernel<3>, g, b, 0, st, p); break;
+    case 4: hipLaunchKernelGGL(trace_kernel<4>, g, b, 0, st, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gprx

@@ -1,0 +1,167 @@
+// Stationary kernel-matrix build (RBF, Matern-1/2, -3/2, -5/2, gpflow "Exponential").
+//
+//   out[i, j] = variance * g(r2(a_i, b_j)) + (i == j ? diag_add : 0),
+//   r2 = sum_k ((a_ik - b_jk) / l_k)^2      (difference form: no cancellation, r2(a, a) == 0)
+//
+// Replaces gpflow's kernel evaluation inside SGPR (Kuf, Kuu, Kus; k(X, X) + s I for the exact
+// specialisation).  HBM-write bound: each 64 x 64 output tile costs 32 KiB of stores against
+// 2 x 64 x d inputs, so the layout goal is full-line stores -- a wave stores two rows of
+// 32 x 16 B = 512 contiguous bytes per instruction -- and no reload of the inputs: the
+// (scaled) coordinates of the 64 + 64 points of a tile are staged once through LDS.
+#pragma once
+#include "gprx_common.h"
+
+namespace gprx {
+
+constexpr int KM_T = 64;   // tile edge
+constexpr int KM_DC = 8;   // coordinates staged per LDS pass
+
+template <int KID>
+__device__ __forceinline__ double corr_g(double r2) {
+  if constexpr (KID == 0) {
+    return exp(-0.5 * r2);
+  } else {
+    const double r = sqrt(fmax(r2, R2_FLOOR));
+    if constexpr (KID == 1) return exp(-r);
+    if constexpr (KID == 2) {
+      const double t = 1.7320508075688772 * r;
+      return (1.0 + t) * exp(-t);
+    }
+    if constexpr (KID == 3) {
+      const double t = 2.23606797749979 * r;
+      return (1.0 + t + (5.0 / 3.0) * r * r) * exp(-t);
+    }
+    return exp(-0.5 * r);
+  }
+}
+
+// g and h = 2 dg/d(r2) = g'(r)/r together (h == 0 where gpflow's max(r2, 1e-36) stops the gradient)
+template <int KID>
+__device__ __forceinline__ void corr_gh(double r2, double& g, double& h) {
+  if constexpr (KID == 0) {
+    g = exp(-0.5 * r2);
+    h = -g;
+  } else {
+    const bool live = r2 >= R2_FLOOR;
+    const double r = sqrt(fmax(r2, R2_FLOOR));
+    if constexpr (KID == 1) {
+      g = exp(-r);
+      h = -g / r;
+    } else if constexpr (KID == 2) {
+      const double t = 1.7320508075688772 * r;
+      const double e = exp(-t);
+      g = (1.0 + t) * e;
+      h = -3.0 * e;
+    } else if constexpr (KID == 3) {
+      const double t = 2.23606797749979 * r;
+      const double e = exp(-t);
+      g = (1.0 + t + (5.0 / 3.0) * r * r) * e;
+      h = -(5.0 / 3.0) * (1.0 + t) * e;
+    } else {
+      g = exp(-0.5 * r);
+      h = -0.5 * g / r;
+    }
+    if (!live) h = 0.0;
+  }
+}
+
+struct KmatArgs {
+  const double* a;       // (n1, d)
+  const double* b;       // (n2, d)
+  const double* inv_ls;  // d values, device
+  double* out;
+  int64_t ld;
+  int n1, n2, d;
+  int n1p, n2p;          // padded extents actually written
+  double variance, diag_add;
+  int mode;              // 0: rectangle (zero padding), 1: symmetric, tiles on/below the diagonal only, 2: symmetric, all tiles
+  double pad_diag;       // value written on the diagonal of the padding (1 for symmetric modes, else 0)
+  int tiles_n;
+};
+
+// Stage KM_DC scaled coordinates of 64 points: sA[point][KM_DC] (row broadcast reads),
+// sBt[KM_DC][64] (lane-contiguous reads).
+template <int KID>
+__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
+  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  const int ti = blockIdx.x / p.tiles_n, tj = blockIdx.x % p.tiles_n;
+  if (p.mode == 1 && tj > ti) return;
+  const int i0 = ti * KM_T, j0 = tj * KM_T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cp = lane & 31, rsub = lane >> 5;
+
+  double acc[8][2];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) acc[it][0] = acc[it][1] = 0.0;
+
+  for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
+    // 64 points x 8 coords for each side = 512 + 512 values, 256 threads -> 2 + 2 each
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int q = tid + 256 * rep;
+      const int pt = q >> 3, kk = q & 7;
+      const int k = k0 + kk;
+      double va = 0.0, vb = 0.0;
+      if (k < p.d) {
+        const double s = p.inv_ls[k];
+        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] * s;
+        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] * s;
+      }
+      sA[pt][kk] = va;
+      sBt[kk][pt] = vb;
+    }
+    __syncthreads();
+    double b0[KM_DC], b1[KM_DC];
+#pragma unroll
+    for (int kk = 0; kk < KM_DC; ++kk) {
+      const d2 v = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
+      b0[kk] = v.x;
+      b1[kk] = v.y;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = wave * 16 + 2 * it + rsub;
+#pragma unroll
+      for (int kk = 0; kk < KM_DC; ++kk) {
+        const double a = sA[row][kk];
+        const double d0 = a - b0[kk], d1 = a - b1[kk];
+        acc[it][0] = __builtin_fma(d0, d0, acc[it][0]);
+        acc[it][1] = __builtin_fma(d1, d1, acc[it][1]);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = i0 + wave * 16 + 2 * it + rsub;
+    const int j = j0 + 2 * cp;
+    if (i >= p.n1p || j >= p.n2p) continue;
+    d2 v;
+    const bool vi = i < p.n1;
+    v.x = (vi && j < p.n2) ? p.variance * corr_g<KID>(acc[it][0]) : 0.0;
+    v.y = (vi && j + 1 < p.n2) ? p.variance * corr_g<KID>(acc[it][1]) : 0.0;
+    if (i == j) v.x += (vi && j < p.n2) ? p.diag_add : p.pad_diag;
+    if (i == j + 1) v.y += (vi && j + 1 < p.n2) ? p.diag_add : p.pad_diag;
+    *reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j) = v;
+  }
+}
+
+inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p) {
+  const int tiles_m = (p.n1p + KM_T - 1) / KM_T;
+  p.tiles_n = (p.n2p + KM_T - 1) / KM_T;
+  if (tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
+  dim3 grid(tiles_m * p.tiles_n), block(256);
+  switch (kid) {
+    case 0: hipLaunchKernelGGL(kmat_kernel<0>, grid, block, 0, st, p); break;
+    case 1: hipLaunchKernelGGL(kmat_kernel<1>, grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL(kmat_kernel<2>, grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL(kmat_kernel<3>, grid, block, 0, st, p); break;
+    case 4: hipLaunchKernelGGL(kmat_kernel<4>, grid, block, 0, st, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gprx

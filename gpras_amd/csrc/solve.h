@@ -1,0 +1,220 @@
+// Triangular solves, inversion and reductions built on the 64 x 64 diagonal-block inverses
+// that potrf_panel_kernel leaves behind.
+#pragma once
+#include "gemm_f64.h"
+#include "gprx_common.h"
+
+namespace gprx {
+
+// ---- vector right-hand side ------------------------------------------------------------------
+// One launch per diagonal block.  Step i of the forward solve L x = b:
+//   every workgroup j > i:  b_j -= L[j, i] x_i   (64 rows x 64 cols, 16 lanes per row)
+//   workgroup j == i + 1 then forms x_{i+1} = invD_{i+1} b_{i+1}.
+// Step -1 (first launch) only forms x_0.  x overwrites b.
+__global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
+                                                     double* __restrict__ b, int i, int nblocks) {
+  __shared__ double sx[NB];
+  __shared__ double sb[NB];
+  const int t = threadIdx.x;
+  const int j = i + 1 + blockIdx.x;  // block row handled here
+  if (j >= nblocks) return;
+  if (i >= 0) {
+    if (t < NB) sx[t] = b[i * NB + t];
+    __syncthreads();
+    const int part = t & 15, rr = t >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = rr + 16 * pass;
+      const double* lp = L + (int64_t)(j * NB + r) * lda + i * NB + part * 4;
+      const d2 v0 = *reinterpret_cast<const d2*>(lp);
+      const d2 v1 = *reinterpret_cast<const d2*>(lp + 2);
+      double s = v0.x * sx[part * 4] + v0.y * sx[part * 4 + 1] + v1.x * sx[part * 4 + 2] + v1.y * sx[part * 4 + 3];
+      s += __shfl_xor(s, 8, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 1, 64);
+      if (part == 0) {
+        const double nb_ = b[j * NB + r] - s;
+        b[j * NB + r] = nb_;
+        sb[r] = nb_;
+      }
+    }
+  } else {
+    if (t < NB) sb[t] = b[j * NB + t];
+  }
+  if (j != i + 1) return;
+  __syncthreads();
+  if (t < NB) {
+    const double* ip = inv_diag + (int64_t)j * NB * NB + t * NB;
+    double s = 0.0;
+    for (int m = 0; m <= t; ++m) s = __builtin_fma(ip[m], sb[m], s);
+    b[j * NB + t] = s;
+  }
+}
+
+// Step i of the backward solve L^T x = b (i runs from nblocks-1 down):
+//   every workgroup j < i:  b_j -= L[i, j]^T x_i   (thread per column, 64 rows of the block row i)
+//   workgroup j == i - 1 then forms x_{i-1} = invD_{i-1}^T b_{i-1}.
+// Step i == nblocks only forms x_{nblocks-1}.
+__global__ __launch_bounds__(64) void trsv_bwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
+                                                    double* __restrict__ b, int i, int nblocks) {
+  __shared__ double sx[NB];
+  __shared__ double sb[NB];
+  const int t = threadIdx.x;
+  const int j = i - 1 - (int)blockIdx.x;
+  if (j < 0) return;
+  double v = b[j * NB + t];
+  if (i < nblocks) {
+    sx[t] = b[i * NB + t];
+    __syncthreads();
+    const double* lp = L + (int64_t)(i * NB) * lda + j * NB + t;
+    double s = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < NB; ++m) s = __builtin_fma(lp[(int64_t)m * lda], sx[m], s);
+    v -= s;
+    b[j * NB + t] = v;
+  }
+  if (j != i - 1) return;
+  sb[t] = v;
+  __syncthreads();
+  const double* ip = inv_diag + (int64_t)j * NB * NB;
+  double s = 0.0;
+  for (int m = t; m < NB; ++m) s = __builtin_fma(ip[m * NB + t], sb[m], s);
+  b[j * NB + t] = s;
+}
+
+inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* b, int np, bool transpose) {
+  const int nblocks = np / NB;
+  if (!transpose) {
+    for (int i = -1; i < nblocks - 1; ++i)
+      hipLaunchKernelGGL(trsv_fwd_step, dim3(i < 0 ? 1 : nblocks - 1 - i), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks);
+  } else {
+    for (int i = nblocks; i >= 1; --i)
+      hipLaunchKernelGGL(trsv_bwd_step, dim3(i == nblocks ? 1 : i), dim3(64), 0, st, L, lda, inv_diag, b, i, nblocks);
+  }
+  return hipGetLastError();
+}
+
+// ---- matrix right-hand side: L X = B (in place), recursive halving onto MFMA GEMMs -------------
+inline hipError_t trsm_lower_left(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* B, int64_t ldb,
+                                  int n, int ncols) {
+  if (n == NB) return launch_gemm(st, 0, 0, NB, ncols, NB, 1.0, inv_diag, NB, B, ldb, 0.0, B, ldb, GEMM_A_LOWER, 64);
+  const int n1 = (n / NB / 2) * NB, n2 = n - n1;
+  hipError_t e = trsm_lower_left(st, L, lda, inv_diag, B, ldb, n1, ncols);
+  if (e != hipSuccess) return e;
+  e = launch_gemm(st, 0, 0, n2, ncols, n1, -1.0, L + (int64_t)n1 * lda, lda, B, ldb, 1.0, B + (int64_t)n1 * ldb, ldb, 0);
+  if (e != hipSuccess) return e;
+  return trsm_lower_left(st, L + (int64_t)n1 * lda + n1, lda, inv_diag + (int64_t)(n1 / NB) * NB * NB, B + (int64_t)n1 * ldb, ldb, n2,
+                         ncols);
+}
+
+// L^T X = B (in place)
+inline hipError_t trsm_lower_left_t(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* B, int64_t ldb,
+                                    int n, int ncols) {
+  if (n == NB) return launch_gemm(st, 1, 0, NB, ncols, NB, 1.0, inv_diag, NB, B, ldb, 0.0, B, ldb, GEMM_A_UPPER, 64);
+  const int n1 = (n / NB / 2) * NB, n2 = n - n1;
+  hipError_t e = trsm_lower_left_t(st, L + (int64_t)n1 * lda + n1, lda, inv_diag + (int64_t)(n1 / NB) * NB * NB,
+                                   B + (int64_t)n1 * ldb, ldb, n2, ncols);
+  if (e != hipSuccess) return e;
+  // B1 -= L21^T X2 : op(A) = L21^T with L21 stored (n2 x n1)
+  e = launch_gemm(st, 1, 0, n1, ncols, n2, -1.0, L + (int64_t)n1 * lda, lda, B + (int64_t)n1 * ldb, ldb, 1.0, B, ldb, 0);
+  if (e != hipSuccess) return e;
+  return trsm_lower_left_t(st, L, lda, inv_diag, B, ldb, n1, ncols);
+}
+
+// ---- inverse of the Cholesky factor: X = L^-1 (lower), recursive, two GEMMs per node ------------
+__global__ __launch_bounds__(256) void scatter_inv_diag(const double* __restrict__ inv_diag, double* __restrict__ X, int64_t ldx) {
+  const int blk = blockIdx.x;
+  const double* src = inv_diag + (int64_t)blk * NB * NB;
+  double* dst = X + (int64_t)blk * NB * ldx + blk * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    dst[(int64_t)r * ldx + c] = src[e];
+  }
+}
+
+inline hipError_t trtri_rec(hipStream_t st, const double* L, int64_t lda, double* X, int64_t ldx, double* T, int64_t ldt, int n) {
+  if (n == NB) return hipSuccess;
+  const int n1 = (n / NB / 2) * NB, n2 = n - n1;
+  hipError_t e = trtri_rec(st, L, lda, X, ldx, T, ldt, n1);
+  if (e != hipSuccess) return e;
+  e = trtri_rec(st, L + (int64_t)n1 * lda + n1, lda, X + (int64_t)n1 * ldx + n1, ldx, T + (int64_t)n1 * ldt + n1, ldt, n2);
+  if (e != hipSuccess) return e;
+  // T21 = L21 X11   (X11 lower triangular)
+  e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L + (int64_t)n1 * lda, lda, X, ldx, 0.0, T + (int64_t)n1 * ldt, ldt, GEMM_B_LOWER);
+  if (e != hipSuccess) return e;
+  // X21 = -X22 T21  (X22 lower triangular)
+  return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X + (int64_t)n1 * ldx + n1, ldx, T + (int64_t)n1 * ldt, ldt, 0.0,
+                     X + (int64_t)n1 * ldx, ldx, GEMM_A_LOWER);
+}
+
+inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* X, int64_t ldx, double* T,
+                              int64_t ldt, int np) {
+  hipLaunchKernelGGL(scatter_inv_diag, dim3(np / NB), dim3(256), 0, st, inv_diag, X, ldx);
+  return trtri_rec(st, L, lda, X, ldx, T, ldt, np);
+}
+
+// ---- reductions ----------------------------------------------------------------------------------
+// out[0] = sum_i log L[i,i] (i < n), out[1] = sum_i v[i]^2 (i < n)
+__global__ __launch_bounds__(256) void logdet_quad_kernel(const double* __restrict__ L, int64_t lda, const double* __restrict__ v, int n,
+                                                          double* __restrict__ out) {
+  __shared__ double s0[4], s1[4];
+  double a = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    a += log(L[(int64_t)i * lda + i]);
+    if (v) q = __builtin_fma(v[i], v[i], q);
+  }
+  a = wave_sum(a);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) {
+    s0[threadIdx.x >> 6] = a;
+    s1[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = s0[0] + s0[1] + s0[2] + s0[3];
+    out[1] = s1[0] + s1[1] + s1[2] + s1[3];
+  }
+}
+
+// partial[chunk][t] = sum over the chunk's rows of  w[row] * M[row, t]   (w != null)
+//                                             or  M[row, t]^2            (w == null)
+__global__ __launch_bounds__(256) void colreduce_partial(const double* __restrict__ M, int64_t ldm, const double* __restrict__ w, int nrows,
+                                                         int ncols, int rows_per_chunk, double* __restrict__ partial) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ncols) return;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(nrows, r0 + rows_per_chunk);
+  double s0 = 0.0, s1 = 0.0;
+  int r = r0;
+  if (w) {
+    for (; r + 1 < r1; r += 2) {
+      s0 = __builtin_fma(w[r], M[(int64_t)r * ldm + t], s0);
+      s1 = __builtin_fma(w[r + 1], M[(int64_t)(r + 1) * ldm + t], s1);
+    }
+    if (r < r1) s0 = __builtin_fma(w[r], M[(int64_t)r * ldm + t], s0);
+  } else {
+    for (; r + 1 < r1; r += 2) {
+      const double a = M[(int64_t)r * ldm + t], b = M[(int64_t)(r + 1) * ldm + t];
+      s0 = __builtin_fma(a, a, s0);
+      s1 = __builtin_fma(b, b, s1);
+    }
+    if (r < r1) {
+      const double a = M[(int64_t)r * ldm + t];
+      s0 = __builtin_fma(a, a, s0);
+    }
+  }
+  partial[(int64_t)blockIdx.y * ncols + t] = s0 + s1;
+}
+
+// out[t] = base + scale * sum_chunks partial[chunk][t]
+__global__ __launch_bounds__(256) void colreduce_final(const double* __restrict__ partial, int nchunks, int ncols, double base, double scale,
+                                                       double* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ncols) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * ncols + t];
+  out[t] = base + scale * s;
+}
+
+}  // namespace gprx

@@ -1,0 +1,157 @@
+/*
+ * gprx.h -- C ABI of the MI355X-native GP regression engine (libgprx.so).
+ *
+ * Drop-in boundary for the hot path of fema-ffrd/gpras.  The reference has NO FFI or
+ * plugin interface for this path: its boundary is the Python class GPRAS
+ * (/root/reference/gpras/gpr.py:217-384) whose arithmetic is delegated to gpflow's SGPR.
+ * Each entry point below names the reference lines whose work it replaces; the Python
+ * shim that a gpras maintainer would bind (ctypes) is gpras_amd/_lib.py and
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is IEEE binary64 ("f64").
+ *   - host matrices are C-contiguous row-major (what numpy hands over after
+ *     x.astype(np.float64), gpr.py:265-266, :333).  The caller owns every host buffer;
+ *     the library copies during the call and never keeps a host pointer.
+ *   - every function returns an int status (GPRX_OK == 0).  No C++ exception crosses the
+ *     boundary.  gprx_last_error() returns a message for the last failure on that handle
+ *     (or, with a NULL handle, of the calling thread's last handle-less failure).
+ *   - a handle is bound to one device and one HIP stream and is NOT thread-safe; different
+ *     handles may be driven from different host threads / processes (one per GPU).
+ *   - "unconstrained" parameters are the optimiser's variables: softplus^-1 of kernel
+ *     variance and lengthscale(s), softplus^-1(noise - 1e-6) for the likelihood variance
+ *     (gpflow positive() / Gaussian likelihood lower bound, as used at gpr.py:298-305).
+ *     theta = [w_variance, w_lengthscale[0..n_len-1], w_noise],  n_len = ard ? d : 1.
+ *   - device-pointer variants (suffix _dev) take pointers obtained from gprx_dev_malloc or
+ *     from any allocator of the same HIP runtime (e.g. torch.Tensor.data_ptr()).
+ */
+#ifndef GPRX_H
+#define GPRX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPRX_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define GPRX_OK 0
+#define GPRX_EINVAL 1  /* bad argument                       -> ValueError / KeyError   */
+#define GPRX_ENOTPD 2  /* Cholesky hit a non-positive pivot  -> numpy.linalg.LinAlgError */
+#define GPRX_EHIP 3    /* HIP runtime error                  -> RuntimeError            */
+#define GPRX_ENOMEM 4  /* device allocation failed           -> MemoryError             */
+#define GPRX_ESTATE 5  /* call order violated (e.g. predict before factorize)           */
+
+/* kernel ids: the five stationary kernels KERNEL_FACTORY (gpr.py:21-37) can construct
+ * with kernel(variance=, lengthscales=) at gpr.py:298 */
+#define GPRX_KERNEL_RBF 0
+#define GPRX_KERNEL_MATERN12 1
+#define GPRX_KERNEL_MATERN32 2
+#define GPRX_KERNEL_MATERN52 3
+#define GPRX_KERNEL_EXPONENTIAL 4
+
+/* trainable mask bits (gpflow.set_trainable at gpr.py:48-49, 115-125, 133-143) */
+#define GPRX_TRAIN_VARIANCE 1
+#define GPRX_TRAIN_LENGTHSCALE 2
+#define GPRX_TRAIN_NOISE 4
+#define GPRX_TRAIN_Z 8
+
+typedef struct gprx_ctx* gprx_handle;
+
+/* ---- library / device -------------------------------------------------------------- */
+int gprx_version(void);
+const char* gprx_last_error(gprx_handle h);
+int gprx_device_count(int* count);
+
+/* ---- model handle ------------------------------------------------------------------ */
+/* One handle = one training set x (n, d) shared by n_units output columns, i.e. the list
+ * self.models that GPRAS._init_models builds (gpr.py:277-308).  m = number of inducing
+ * points (SGPR, gpr.py:299); m == 0 selects the exact GP (Z = X specialisation). */
+int gprx_create(int device, int64_t n, int d, int64_t m, int kernel_id, int ard, gprx_handle* out);
+int gprx_destroy(gprx_handle h);
+/* run all work of this handle on an existing HIP stream (e.g. torch's current stream) */
+int gprx_set_stream(gprx_handle h, void* hip_stream);
+int gprx_synchronize(gprx_handle h);
+
+/* x: (n, d) row-major, y: (n, n_units) row-major -- the arrays GPRAS.fit stores after the
+ * float64 cast (gpr.py:265-266). */
+int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units);
+
+/* SGPR.training_loss() and its gradient w.r.t. the unconstrained variables (replaces the
+ * GradientTape / gpflow.optimizers.Scipy evaluations at gpr.py:61-62, 95, 127, 153-155,
+ * 186-188, 197-203).  LogNormal(0,1) log-priors (gpr.py:303-305) are added for the
+ * parameters whose mask bit is set, as gpflow does for trainable parameters.
+ *   theta : n_theta = 2 + n_len unconstrained values
+ *   z     : (m, d) inducing inputs, ignored (may be NULL) when m == 0
+ *   loss  : out, scalar
+ *   grad  : out or NULL; n_theta values followed by m*d values for Z; entries of
+ *           parameters whose mask bit is clear are written as 0.
+ * Leaves the factorisation resident, so gprx_predict may follow for the same (unit, theta, z). */
+int gprx_objective(gprx_handle h, int unit, const double* theta, const double* z, int mask, double* loss, double* grad);
+
+/* Factorise only (kernel build + Cholesky + weights); what SGPR.predict_y recomputes on
+ * every call at gpr.py:337.  loss may be NULL; otherwise receives the training loss with
+ * priors for the parameters in mask. */
+int gprx_factorize(gprx_handle h, int unit, const double* theta, const double* z, int mask, double* loss);
+
+/* SGPR.predict_y (gpr.py:336-339): predictive mean and variance at xs (ns, d) for the unit
+ * factorised last.  include_noise != 0 adds the likelihood variance (predict_y); 0 gives
+ * predict_f.  mean/var: ns values each. */
+int gprx_predict(gprx_handle h, const double* xs, int64_t ns, double* mean, double* var, int include_noise);
+/* same, every pointer is a device pointer; asynchronous on the handle's stream */
+int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* mean_dev, double* var_dev, int include_noise);
+
+/* timings (ms, HIP events on the handle's stream) of the stages of the last
+ * gprx_objective / gprx_factorize call: [kernel build, cholesky, solves, gradient]. */
+int gprx_last_timings(gprx_handle h, double* ms4);
+
+/* ---- batched small problems ------------------------------------------------------- */
+/* Evaluate loss (+ gradient) for `count` units in one call: units[i] with theta row i
+ * (count, n_theta) and z block i (count, m, d).  Replaces the serial loop over
+ * self.models at gpr.py:272-274.  losses: count values; grads: (count, n_theta + m*d) or NULL. */
+int gprx_objective_batch(gprx_handle h, int count, const int* units, const double* theta, const double* z, int mask,
+                         double* losses, double* grads);
+
+/* ---- device memory helpers (for callers that keep inputs resident in HBM) ----------- */
+int gprx_dev_malloc(int device, int64_t bytes, void** out);
+int gprx_dev_free(int device, void* ptr);
+int gprx_memcpy_h2d(int device, void* dst_dev, const void* src_host, int64_t bytes);
+int gprx_memcpy_d2h(int device, void* dst_host, const void* src_dev, int64_t bytes);
+
+/* ---- building blocks (exported for parity tests, profiling and bench.py) ----------- */
+/* All matrices row-major f64 in device memory, leading dimension in elements.  These run on
+ * the NULL stream of `device` and synchronise before returning unless noted. */
+
+/* out[i, j] = variance * g(r(a_i, b_j)) + (i == j ? diag_add : 0)
+ * a: (n1, d), b: (n2, d) device, inv_ls: d host values (1 / lengthscale per dimension).
+ * mode 0: all of the (n1p, n2p) padded rectangle; mode 1: a == b, only tiles on or below the
+ * diagonal are written (what the Cholesky reads).  Padding (i >= n1 or j >= n2): identity. */
+int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const double* b_dev, int64_t n2, int d,
+              const double* inv_ls_host, double variance, double diag_add, double* out_dev, int64_t ld, int64_t n1p,
+              int64_t n2p, int mode);
+
+/* C = alpha * op(A) op(B) + beta * C;  ta/tb: 0 = as stored, 1 = transposed.  Supported:
+ * (ta,tb) in {(0,1), (0,0), (1,0)}.  k must be a multiple of 16.  flags: GPRX_GEMM_* */
+#define GPRX_GEMM_C_LOWER 1  /* compute only tiles touching the lower triangle of C            */
+#define GPRX_GEMM_A_LOWER 2  /* op(A)[i,k] == 0 for k > i  (skip zero tiles)                  */
+#define GPRX_GEMM_A_UPPER 4  /* op(A)[i,k] == 0 for k < i                                     */
+#define GPRX_GEMM_B_LOWER 8  /* op(B)[k,j] == 0 for k < j                                     */
+#define GPRX_GEMM_B_UPPER 16 /* op(B)[k,j] == 0 for k > j                                     */
+int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* a_dev, int64_t lda,
+              const double* b_dev, int64_t ldb, double beta, double* c_dev, int64_t ldc, int flags, int tile);
+
+/* In-place lower Cholesky of the (np, np) matrix (np multiple of 64) with `extra` right-hand
+ * side rows stored below it (rows np .. np+extra-1, each of length np): on return the lower
+ * triangle holds L, the extra rows hold (L^-1 rhs)^T, inv_diag (np/64 blocks of 64x64) holds
+ * the inverses of the diagonal blocks.  info_host: 0, or 1-based index of the failing pivot. */
+int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra, double* inv_diag_dev, int* info_host);
+
+/* measured back-to-back v_mfma_f64_16x16x4_f64 rate of the whole chip, TFLOP/s */
+int gprx_mfma_f64_peak(int device, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPRX_H */

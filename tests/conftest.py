@@ -1,0 +1,35 @@
+"""pytest configuration: the `gpu` marker separates MI355X parity tests from the CPU suite."""
+
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _gpu_present() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def lib():
+    """libgprx.so through the C ABI; GPU tests fail loudly (no skip) when it is missing on a GPU box."""
+    from gpras_amd import _lib
+
+    return _lib.load()
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_present():
+        return
+    skip = pytest.mark.skip(reason="no GPU device in this container (/dev/kfd absent)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,140 @@
+"""GPU parity of the building-block kernels, called through the C ABI, against numpy / the oracle.
+
+Tolerances are for fp64: elementwise kernels 1e-13 relative, factorizations 1e-11 (they are
+backward stable, the bound scales with the condition number of the test matrix).
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.linalg import cholesky, solve_triangular
+
+from gpras_amd import _lib
+from gpras_amd._lib import DeviceBuffer, check, ptr
+from oracle import kernels as okn
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_mfma_f64_layout_asymmetric(lib):
+    """A = I with an asymmetric B catches a swapped C/D lane map (guide section 3)."""
+    n = 64
+    a = np.eye(n)
+    b = np.arange(n * n, dtype=np.float64).reshape(n, n) * 0.5 + 1.0  # asymmetric
+    dA, dB, dC = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b), DeviceBuffer(n * n * 8)
+    check(lib.gprx_gemm(0, 0, 0, n, n, n, 1.0, dA.ptr, n, dB.ptr, n, 0.0, dC.ptr, n, 0, 64))
+    assert np.array_equal(dC.to_array((n, n)), b)
+    check(lib.gprx_gemm(0, 0, 1, n, n, n, 1.0, dA.ptr, n, dB.ptr, n, 0.0, dC.ptr, n, 0, 64))
+    assert np.array_equal(dC.to_array((n, n)), b.T)
+    check(lib.gprx_gemm(0, 1, 0, n, n, n, 1.0, dB.ptr, n, dA.ptr, n, 0.0, dC.ptr, n, 0, 64))
+    assert np.array_equal(dC.to_array((n, n)), b.T)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", [(256, 192, 64), (200, 136, 48), (64, 1000, 128), (384, 384, 256)])
+def test_gemm_vs_numpy(lib, ta, tb, tile, shape):
+    m, n, k = shape
+    rng = np.random.default_rng(m * 7 + n * 3 + k + ta * 2 + tb)
+    a = rng.standard_normal((k, m) if ta else (m, k))
+    b = rng.standard_normal((n, k) if tb else (k, n))
+    c0 = rng.standard_normal((m, n))
+    ref = 0.7 * (a.T if ta else a) @ (b.T if tb else b) - 1.3 * c0
+    dA, dB, dC = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b), DeviceBuffer.from_array(c0)
+    check(lib.gprx_gemm(0, ta, tb, m, n, k, 0.7, dA.ptr, a.shape[1], dB.ptr, b.shape[1], -1.3, dC.ptr, n, 0, tile))
+    got = dC.to_array((m, n))
+    assert rel_err(got, ref) < 1e-13
+
+
+def test_gemm_triangular_flags(lib):
+    """Zero-tile skipping must give the same product as the dense call on explicitly triangular operands."""
+    n = 320
+    rng = np.random.default_rng(5)
+    lo = np.tril(rng.standard_normal((n, n)))
+    de = rng.standard_normal((n, n))
+    dL, dD, dC = DeviceBuffer.from_array(lo), DeviceBuffer.from_array(de), DeviceBuffer(n * n * 8)
+    for tile in (64, 128):
+        check(lib.gprx_gemm(0, 0, 0, n, n, n, 1.0, dL.ptr, n, dD.ptr, n, 0.0, dC.ptr, n, _lib.GEMM_A_LOWER, tile))
+        assert rel_err(dC.to_array((n, n)), lo @ de) < 1e-13
+        check(lib.gprx_gemm(0, 0, 0, n, n, n, 1.0, dD.ptr, n, dL.ptr, n, 0.0, dC.ptr, n, _lib.GEMM_B_LOWER, tile))
+        assert rel_err(dC.to_array((n, n)), de @ lo) < 1e-13
+        # X^T X with X lower: op(A) upper, B lower, lower tiles of C only
+        check(lib.gprx_gemm(0, 1, 0, n, n, n, 1.0, dL.ptr, n, dL.ptr, n, 0.0, dC.ptr, n,
+                            _lib.GEMM_C_LOWER | _lib.GEMM_A_UPPER | _lib.GEMM_B_LOWER, tile))
+        got = np.tril(dC.to_array((n, n)))
+        assert rel_err(got, np.tril(lo.T @ lo)) < 1e-13
+
+
+@pytest.mark.parametrize("kernel", okn.KERNEL_NAMES)
+@pytest.mark.parametrize("ard", [False, True])
+def test_kmat_vs_oracle(lib, kernel, ard):
+    rng = np.random.default_rng(11)
+    n1, n2, d = 150, 200, 5
+    a, b = rng.standard_normal((n1, d)), rng.standard_normal((n2, d))
+    b[:20] = a[:20]  # coincident points: r2 == 0 exactly
+    ls = rng.uniform(0.5, 2.0, size=d) if ard else np.full(d, 0.8)
+    n1p, n2p = 192, 256
+    dA, dB, dO = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b), DeviceBuffer(n1p * n2p * 8)
+    inv = np.ascontiguousarray(1.0 / ls)
+    check(lib.gprx_kmat(0, okn.KERNEL_IDS[kernel], dA.ptr, n1, dB.ptr, n2, d, ptr(inv), 1.7, 0.0, dO.ptr, n2p, n1p, n2p, 0))
+    got = dO.to_array((n1p, n2p))
+    ref = okn.kmat(kernel, a, b, 1.7, ls)
+    assert rel_err(got[:n1, :n2], ref) < 1e-13
+    assert np.all(got[n1:, :] == 0.0) and np.all(got[:, n2:] == 0.0)
+    # symmetric, lower tiles, identity padding, diagonal term
+    dS = DeviceBuffer(n1p * n1p * 8)
+    check(lib.gprx_kmat(0, okn.KERNEL_IDS[kernel], dA.ptr, n1, dA.ptr, n1, d, ptr(inv), 1.7, 0.25, dS.ptr, n1p, n1p, n1p, 2))
+    got = dS.to_array((n1p, n1p))
+    ref = okn.kmat(kernel, a, a, 1.7, ls) + 0.25 * np.eye(n1)
+    assert rel_err(got[:n1, :n1], ref) < 1e-13
+    assert np.array_equal(got[n1:, n1:], np.eye(n1p - n1))
+    assert np.all(got[:n1, n1:] == 0.0) and np.all(got[n1:, :n1] == 0.0)
+    assert np.array_equal(np.diag(got)[:n1], np.full(n1, 1.7 + 0.25))  # r2(a, a) == 0 exactly
+
+
+@pytest.mark.parametrize("n,extra", [(64, 0), (128, 64), (448, 64), (1024, 128)])
+def test_potrf_vs_scipy(lib, n, extra):
+    rng = np.random.default_rng(n)
+    g = rng.standard_normal((n, n + 8))
+    spd = g @ g.T / n + 0.5 * np.eye(n)
+    rhs = rng.standard_normal((extra, n))
+    full = np.vstack([np.tril(spd) + np.triu(np.full((n, n), np.nan), 1), rhs])  # NaN above the diagonal: must never be read
+    # the diagonal 64-blocks are read in full by the symmetric update of the GEMM: keep them finite there
+    for b0 in range(0, n, 64):
+        full[b0 : b0 + 64, b0 : b0 + 64] = spd[b0 : b0 + 64, b0 : b0 + 64]
+    dA = DeviceBuffer.from_array(full)
+    dI = DeviceBuffer(n * 64 * 8)
+    info = C.c_int(-1)
+    check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
+    assert info.value == 0
+    out = dA.to_array((n + extra, n))
+    L_ref = cholesky(spd, lower=True)
+    L = np.zeros((n, n))
+    for b0 in range(0, n, 64):  # compare the lower part block row by block row
+        L[b0 : b0 + 64, : b0 + 64] = out[b0 : b0 + 64, : b0 + 64]
+    assert np.all(np.triu(L, 1) == 0.0)
+    assert rel_err(L, L_ref) < 1e-11
+    if extra:
+        beta_ref = solve_triangular(L_ref, rhs.T, lower=True).T
+        assert rel_err(out[n:], beta_ref) < 1e-11
+    inv = dI.to_array((n // 64, 64, 64))
+    for i in range(n // 64):
+        blk = L_ref[64 * i : 64 * i + 64, 64 * i : 64 * i + 64]
+        assert rel_err(inv[i], np.linalg.inv(blk)) < 1e-10
+
+
+def test_potrf_reports_failing_pivot(lib):
+    n = 128
+    a = np.eye(n)
+    a[70, 70] = -1.0
+    dA, dI = DeviceBuffer.from_array(a), DeviceBuffer(n * 64 * 8)
+    info = C.c_int(0)
+    rc = lib.gprx_potrf(0, dA.ptr, n, n, 0, dI.ptr, C.byref(info))
+    assert rc == _lib.GPRX_ENOTPD and info.value == 71
+    with pytest.raises(np.linalg.LinAlgError):
+        check(rc)

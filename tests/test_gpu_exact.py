@@ -1,0 +1,88 @@
+"""GPU parity of the exact-GP path (kernel build + blocked MFMA Cholesky + solves + gradient +
+predict) against the CPU oracle, through the C ABI.  Tolerance: 1e-8 relative as BASELINE.json's
+north_star states for predictions; losses and gradients are held to 1e-9 / 1e-7."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpras_amd import _lib
+from gpras_amd._lib import check, ptr
+from gpras_amd.synth import make_regression
+from oracle import exact as oex
+from oracle import kernels as okn
+from oracle import transforms as otr
+
+pytestmark = pytest.mark.gpu
+
+ALL = _lib.TRAIN_VARIANCE | _lib.TRAIN_LENGTHSCALE | _lib.TRAIN_NOISE
+
+
+def make_handle(lib, n, d, kernel, ard, x, y):
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS[kernel], int(ard), C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), y.shape[1]), h)
+    return h
+
+
+def pack_theta(variance, ls, noise):
+    wv, wl, wn = otr.unconstrain(variance, ls, noise)
+    return np.ascontiguousarray(np.concatenate([[wv], np.atleast_1d(wl), [wn]]))
+
+
+@pytest.mark.parametrize("kernel", okn.KERNEL_NAMES)
+@pytest.mark.parametrize("n,d,ard", [(256, 4, False), (300, 5, True), (1000, 8, False)])
+def test_exact_loss_grad_predict(lib, kernel, n, d, ard):
+    x, y, xs = make_regression(n, d, n_outputs=2, n_test=333, config=1, unit=n)
+    h = make_handle(lib, n, d, kernel, ard, x, y)
+    try:
+        ls = np.linspace(0.7, 1.4, d) if ard else 0.9
+        variance, noise = 1.3, 0.07
+        theta = pack_theta(variance, ls, noise)
+        for unit in range(2):
+            loss = C.c_double()
+            grad = np.zeros(theta.size)
+            check(lib.gprx_objective(h, unit, ptr(theta), None, ALL, C.byref(loss), ptr(grad)), h)
+            wl = theta[1:-1] if ard else float(theta[1])
+            ref_loss, ref_g = oex.loss_and_grad(kernel, x, y[:, unit], float(theta[0]), wl, float(theta[-1]))
+            ref_grad = np.concatenate([[ref_g["variance"]], np.atleast_1d(ref_g["lengthscales"]), [ref_g["noise"]]])
+            assert abs(loss.value - ref_loss) <= 1e-9 * abs(ref_loss)
+            assert np.max(np.abs(grad - ref_grad)) <= 1e-7 * np.max(np.abs(ref_grad))
+            mean = np.zeros(xs.shape[0])
+            var = np.zeros(xs.shape[0])
+            check(lib.gprx_predict(h, ptr(xs), xs.shape[0], ptr(mean), ptr(var), 1), h)
+            ref_mean, ref_var = oex.predict(kernel, x, y[:, unit], variance, ls, noise, xs, True)
+            assert np.max(np.abs(mean - ref_mean)) <= 1e-8 * np.max(np.abs(ref_mean))
+            assert np.max(np.abs(var - ref_var) / ref_var) <= 1e-8
+            assert np.all(var >= noise * (1 - 1e-12))  # predictive variance never below the noise floor
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_exact_mask_and_errors(lib):
+    n, d = 128, 3
+    x, y, _ = make_regression(n, d, config=1, unit=7)
+    h = make_handle(lib, n, d, "RBF", False, x, y)
+    try:
+        theta = pack_theta(1.0, 0.8, 0.5)
+        loss = C.c_double()
+        grad = np.ones(3)
+        mask = _lib.TRAIN_NOISE
+        check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
+        ref_loss, ref_g = oex.loss_and_grad("RBF", x, y[:, 0], theta[0], float(theta[1]), theta[2], mask=(False, False, True))
+        assert abs(loss.value - ref_loss) <= 1e-10 * abs(ref_loss)
+        assert grad[0] == 0.0 and grad[1] == 0.0 and abs(grad[2] - ref_g["noise"]) <= 1e-8 * abs(ref_g["noise"])
+        # errors: unit out of range, non-finite theta, predict before factorize on a fresh handle
+        assert lib.gprx_objective(h, 5, ptr(theta), None, mask, C.byref(loss), None) == _lib.GPRX_EINVAL
+        bad = theta.copy()
+        bad[1] = np.nan
+        assert lib.gprx_objective(h, 0, ptr(bad), None, mask, C.byref(loss), None) == _lib.GPRX_EINVAL
+    finally:
+        lib.gprx_destroy(h)
+    h2 = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h2)))
+    out = np.zeros(4)
+    assert lib.gprx_predict(h2, ptr(x), 4, ptr(out), ptr(out), 1) == _lib.GPRX_ESTATE
+    lib.gprx_destroy(h2)
+    assert lib.gprx_create(0, n, d, 0, 9, 0, C.byref(h2)) == _lib.GPRX_EINVAL
