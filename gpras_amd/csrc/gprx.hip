@@ -16,6 +16,7 @@
 #include "grad.h"
 #include "kmat.h"
 #include "potrf.h"
+#include "sgpr.h"
 #include "solve.h"
 
 using namespace gprx;
@@ -40,6 +41,11 @@ struct gprx_ctx {
   std::string err;
   // data
   Buf X, Y, Z, invls, alpha, red, Kmat, invD, Xinv, Tmp, partial, xs, Ks, pred;
+  // sparse path
+  Buf Xp, Zp, P, Am, Qm, Bm, invDL, invDB, SM, WP, WHP, WHQ, vecs, GPx, dZ;
+  std::vector<double> yy;  // y.y per unit
+  int ldp = 0;
+  double elbo_trAAT = 0.0;
   int* info = nullptr;
   // current factorisation
   bool factorized = false;
@@ -74,6 +80,14 @@ int ensure(gprx_handle h, Buf& b, size_t bytes) {
   b.bytes = 0;
   HIPCHK(h, hipMalloc((void**)&b.p, bytes));
   b.bytes = bytes;
+  return GPRX_OK;
+}
+
+int ensure_zeroed(gprx_handle h, Buf& b, size_t bytes) {
+  if (b.bytes >= bytes) return GPRX_OK;
+  int rc = ensure(h, b, bytes);
+  if (rc) return rc;
+  HIPCHK(h, hipMemset(b.p, 0, bytes));
   return GPRX_OK;
 }
 
@@ -141,11 +155,9 @@ double log_prior(gprx_handle h, const Theta& t, int mask) {
   return lp;
 }
 
-int upload_inv_ls(gprx_handle h, const Theta& t) {
-  std::vector<double> inv(h->d);
-  for (int k = 0; k < h->d; ++k) inv[k] = 1.0 / t.ls[k];
-  HIPCHK(h, hipMemcpyAsync(h->invls.p, inv.data(), sizeof(double) * h->d, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // `inv` is a stack temporary
+int upload_inv_ls(gprx_handle h, const Theta& t) {  // uploads the lengthscales (kernels divide by them)
+  HIPCHK(h, hipMemcpyAsync(h->invls.p, t.ls.data(), sizeof(double) * h->d, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return GPRX_OK;
 }
 
@@ -211,7 +223,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   const int tiles = np / KM_T;
   const int width = 2 + h->d;
   if ((rc = ensure(h, h->partial, sizeof(double) * ((size_t)tiles * tiles * width + width)))) return rc;
-  TraceArgs ta{h->X.p, h->X.p, h->invls.p, h->Tmp.p, ld, h->alpha.p, (int)h->n, (int)h->n, h->d, t.variance, 1, h->partial.p, tiles};
+  TraceArgs ta{h->X.p, h->X.p, h->invls.p, h->Tmp.p, ld, h->alpha.p, h->alpha.p, -1.0, 1.0, (int)h->n, (int)h->n, h->d, t.variance, 1, h->partial.p, nullptr, 0, tiles};
   HIPCHK(h, launch_trace(st, h->kid, ta, tiles * tiles));
   double* sums = h->partial.p + (size_t)tiles * tiles * width;
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, h->partial.p, tiles * tiles, width, sums);
@@ -227,6 +239,166 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
     g[1] = 0.5 * s;
   }
   g[1 + h->nlen] = 0.5 * host[1];
+  return GPRX_OK;
+}
+
+
+// ---- sparse GP (SGPR) -----------------------------------------------------------------------------
+// Device restatement of gpflow SGPR._common_calculation / elbo / predict_f (oracle/sgpr.py) with
+//   P = Kuf (mp x np), Q = Kuu + jitter I -> L, A' = L^-1 P (unscaled: A = A' / sqrt(s)),
+//   B = I + A' A'^T / s -> LB, c = LB^-1 A' y / s (carried through the Cholesky as an appended row).
+// SM holds nine mp x mp scratch matrices.
+enum { SM_BFULL = 0, SM_LINV, SM_LBINV, SM_QINV, SM_SINV, SM_R, SM_T1, SM_T2, SM_W, SM_GQ, SM_COUNT };
+
+double* sm(gprx_handle h, int slot) { return h->SM.p + (size_t)slot * h->mp * h->mp; }
+
+int sgpr_alloc(gprx_handle h) {
+  const size_t mp = h->mp, np = h->np;
+  h->ldp = (int)round_up(h->d + 1, 8);
+  int rc;
+  if ((rc = ensure(h, h->Z, sizeof(double) * h->m * h->d))) return rc;
+  if ((rc = ensure(h, h->P, sizeof(double) * mp * np))) return rc;
+  if ((rc = ensure(h, h->Am, sizeof(double) * mp * np))) return rc;
+  if ((rc = ensure(h, h->Qm, sizeof(double) * mp * mp))) return rc;
+  if ((rc = ensure(h, h->Bm, sizeof(double) * (mp + NB) * mp))) return rc;
+  if ((rc = ensure(h, h->invDL, sizeof(double) * mp * NB))) return rc;
+  if ((rc = ensure(h, h->invDB, sizeof(double) * mp * NB))) return rc;
+  if ((rc = ensure_zeroed(h, h->vecs, sizeof(double) * (4 * mp + np)))) return rc;
+  return GPRX_OK;
+}
+
+int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, double* elbo_out) {
+  if (!z) return fail(h, GPRX_EINVAL, "z (inducing inputs) is null for a sparse model");
+  for (int64_t e = 0; e < h->m * h->d; ++e)
+    if (!std::isfinite(z[e])) return fail(h, GPRX_EINVAL, "z is not finite");
+  int rc;
+  if ((rc = sgpr_alloc(h))) return rc;
+  const int mp = (int)h->mp, np = (int)h->np, m = (int)h->m, n = (int)h->n;
+  hipStream_t st = h->stream;
+  HIPCHK(h, hipMemcpyAsync(h->Z.p, z, sizeof(double) * h->m * h->d, hipMemcpyHostToDevice, st));
+  if ((rc = upload_inv_ls(h, t))) return rc;
+  const double s = t.noise;
+  HIPCHK(h, hipEventRecord(h->ev[0], st));
+  KmatArgs kp{h->Z.p, h->X.p, h->invls.p, h->P.p, np, m, n, h->d, mp, np, t.variance, 0.0, 0, 0.0, 0};
+  HIPCHK(h, launch_kmat(st, h->kid, kp));
+  KmatArgs kq{h->Z.p, h->Z.p, h->invls.p, h->Qm.p, mp, m, m, h->d, mp, mp, t.variance, JITTER, 2, 1.0, 0};
+  HIPCHK(h, launch_kmat(st, h->kid, kq));
+  HIPCHK(h, hipEventRecord(h->ev[1], st));
+  HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
+  HIPCHK(h, potrf_lower(st, h->Qm.p, mp, mp, 0, h->invDL.p, h->info));
+  HIPCHK(h, hipMemcpyAsync(h->Am.p, h->P.p, sizeof(double) * (size_t)mp * np, hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, trsm_lower_left(st, h->Qm.p, mp, h->invDL.p, h->Am.p, np, mp, np));
+  // B = I + A' A'^T / s (all of it: the gradient needs the symmetric matrix)
+  HIPCHK(h, launch_gemm(st, 0, 1, mp, mp, np, 1.0 / s, h->Am.p, np, h->Am.p, np, 0.0, h->Bm.p, mp, 0));
+  hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0);
+  hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0, h->red.p + 2);
+  if ((rc = ensure(h, h->SM, sizeof(double) * (size_t)SM_COUNT * mp * mp))) return rc;
+  HIPCHK(h, hipMemcpyAsync(sm(h, SM_BFULL), h->Bm.p, sizeof(double) * (size_t)mp * mp, hipMemcpyDeviceToDevice, st));
+  // appended row: A' y / s  -> comes out of the Cholesky as c
+  double* crow = h->Bm.p + (size_t)mp * mp;
+  HIPCHK(h, hipMemsetAsync(crow, 0, sizeof(double) * (size_t)NB * mp, st));
+  const double* yu = h->Y.p + (size_t)unit * h->np;
+  HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 1.0 / s, h->Am.p, np, yu, 1, 0.0, crow, 1, 0, 64));
+  HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info));
+  HIPCHK(h, hipEventRecord(h->ev[2], st));
+  hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, crow, mp, h->red.p);
+  HIPCHK(h, hipEventRecord(h->ev[3], st));
+  double red[3];
+  int info = 0;
+  HIPCHK(h, hipMemcpyAsync(red, h->red.p, sizeof(red), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (info != 0) {
+    h->factorized = false;
+    char msg[128];
+    snprintf(msg, sizeof msg, "Kuu or B not positive definite: pivot %d", info);
+    return fail(h, GPRX_ENOTPD, msg);
+  }
+  h->factorized = true;
+  h->cur_unit = unit;
+  h->variance = t.variance;
+  h->noise = s;
+  h->ls = t.ls;
+  h->elbo_trAAT = red[2];
+  const double nn = (double)h->n;
+  if (elbo_out)
+    *elbo_out = -0.5 * nn * std::log(2.0 * M_PI) - red[0] - 0.5 * nn * std::log(s) - 0.5 * (nn * t.variance / s - red[2]) -
+                0.5 * (h->yy[unit] / s - red[1]);
+  return GPRX_OK;
+}
+
+// derivatives of the ELBO w.r.t. constrained (variance, lengthscales[nlen], noise) -> g, and Z -> gz (m x d, host)
+int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz) {
+  const int mp = (int)h->mp, np = (int)h->np, m = (int)h->m, n = (int)h->n, d = h->d;
+  const size_t mm = (size_t)mp * mp;
+  const double s = t.noise;
+  hipStream_t st = h->stream;
+  int rc;
+  if ((rc = ensure(h, h->WP, sizeof(double) * (size_t)mp * np))) return rc;
+  if ((rc = ensure_zeroed(h, h->WHP, sizeof(double) * (size_t)mp * np))) return rc;
+  if ((rc = ensure_zeroed(h, h->WHQ, sizeof(double) * mm))) return rc;
+  if ((rc = ensure(h, h->dZ, sizeof(double) * (size_t)m * d))) return rc;
+  const int tiles_m = mp / KM_T, tiles_n = np / KM_T, width = 2 + d;
+  const size_t part_p = (size_t)tiles_m * tiles_n * width, part_q = (size_t)tiles_m * tiles_m * width;
+  if ((rc = ensure(h, h->partial, sizeof(double) * (part_p + part_q + 2 * width)))) return rc;
+  double *Linv = sm(h, SM_LINV), *LBinv = sm(h, SM_LBINV), *Qinv = sm(h, SM_QINV), *Sinv = sm(h, SM_SINV), *R = sm(h, SM_R),
+         *T1 = sm(h, SM_T1), *T2 = sm(h, SM_T2), *W = sm(h, SM_W), *GQ = sm(h, SM_GQ), *Bfull = sm(h, SM_BFULL);
+  double* cvec = h->Bm.p + mm;  // row mp of Bm
+  double* mvec = h->vecs.p;
+  double* qvec = h->vecs.p + 4 * mp;
+  const double* yu = h->Y.p + (size_t)unit * h->np;
+
+  HIPCHK(h, hipMemsetAsync(Linv, 0, sizeof(double) * mm, st));
+  HIPCHK(h, trtri_lower(st, h->Qm.p, mp, h->invDL.p, Linv, mp, T1, mp, mp));
+  HIPCHK(h, hipMemsetAsync(LBinv, 0, sizeof(double) * mm, st));
+  HIPCHK(h, trtri_lower(st, h->Bm.p, mp, h->invDB.p, LBinv, mp, T1, mp, mp));
+  HIPCHK(h, launch_gemm(st, 1, 0, mp, mp, mp, 1.0, Linv, mp, Linv, mp, 0.0, Qinv, mp, GEMM_A_UPPER | GEMM_B_LOWER));
+  HIPCHK(h, launch_gemm(st, 0, 0, mp, mp, mp, 1.0, LBinv, mp, Linv, mp, 0.0, R, mp, GEMM_A_LOWER | GEMM_B_LOWER));
+  HIPCHK(h, launch_gemm(st, 1, 0, mp, mp, mp, 1.0, R, mp, R, mp, 0.0, Sinv, mp, GEMM_A_UPPER | GEMM_B_LOWER));
+  HIPCHK(h, launch_gemm(st, 0, 0, mp, mp, mp, 1.0, Bfull, mp, Linv, mp, 0.0, T2, mp, GEMM_B_LOWER));
+  HIPCHK(h, launch_gemm(st, 1, 0, mp, mp, mp, 1.0, Linv, mp, T2, mp, 0.0, T1, mp, GEMM_A_UPPER));
+  // m = L^-T LB^-T c
+  hipLaunchKernelGGL(copy_row_kernel, dim3((mp + 255) / 256), dim3(256), 0, st, (const double*)cvec, mvec, mp);
+  HIPCHK(h, trsv_lower(st, h->Bm.p, mp, h->invDB.p, mvec, mp, true));
+  HIPCHK(h, trsv_lower(st, h->Qm.p, mp, h->invDL.p, mvec, mp, true));
+  hipLaunchKernelGGL(sgpr_combine_kernel, dim3((mp * mp + 255) / 256), dim3(256), 0, st, (const double*)Qinv, (const double*)Sinv,
+                     (const double*)T1, (const double*)mvec, mp, W, GQ);
+  HIPCHK(h, launch_gemm(st, 0, 0, mp, np, mp, 1.0, W, mp, h->P.p, np, 0.0, h->WP.p, np, 0));
+  // contractions with the kernel derivatives
+  double* partP = h->partial.p;
+  double* partQ = partP + part_p;
+  double* sums = partQ + part_q;
+  TraceArgs tp{h->Z.p, h->X.p, h->invls.p, h->WP.p, np, mvec, yu, 1.0 / s, 1.0 / s, m, n, d, t.variance, 0, partP, h->WHP.p, np, tiles_n};
+  HIPCHK(h, launch_trace(st, h->kid, tp, tiles_m * tiles_n));
+  TraceArgs tq{h->Z.p, h->Z.p, h->invls.p, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, t.variance, 0, partQ, h->WHQ.p, mp, tiles_m};
+  HIPCHK(h, launch_trace(st, h->kid, tq, tiles_m * tiles_m));
+  hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums);
+  hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width);
+  hipLaunchKernelGGL(dz_kernel, dim3(m * d), dim3(256), 0, st, (const double*)h->Z.p, (const double*)h->X.p, (const double*)h->WHP.p,
+                     (int64_t)np, (const double*)h->WHQ.p, (int64_t)mp, (const double*)h->invls.p, m, n, d, h->dZ.p);
+  // noise terms: |y - P^T m|^2 and tr(B^-1) = |LB^-1|_F^2
+  HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, h->P.p, np, mvec, 1, 0.0, qvec, 1, 0, 64));
+  hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1), dim3(256), 0, st, yu, (const double*)qvec, n, h->red.p + 4);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, h->red.p + 3);
+  std::vector<double> hs(2 * width), hz((size_t)m * d);
+  double red[5];
+  HIPCHK(h, hipMemcpyAsync(hs.data(), sums, sizeof(double) * 2 * width, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(red, h->red.p, sizeof(red), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(hz.data(), h->dZ.p, sizeof(double) * m * d, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  const double nn = (double)h->n;
+  const double tr_sinv_pp = s * ((double)mp - red[3]);
+  const double tr_qinv_pp = s * h->elbo_trAAT;
+  g[0] = -nn / (2.0 * s) + hs[0] + hs[width];
+  if (h->ard) {
+    for (int k = 0; k < d; ++k) g[1 + k] = hs[2 + k] + hs[width + 2 + k];
+  } else {
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) acc += hs[2 + k] + hs[width + 2 + k];
+    g[1] = acc;
+  }
+  g[1 + h->nlen] = (tr_sinv_pp - tr_qinv_pp + red[4] + nn * t.variance) / (2.0 * s * s) - nn / (2.0 * s);
+  if (gz) std::memcpy(gz, hz.data(), sizeof(double) * m * d);
   return GPRX_OK;
 }
 
@@ -296,7 +468,8 @@ int gprx_destroy(gprx_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
-                 &h->pred})
+                 &h->pred, &h->Xp, &h->Zp, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs,
+                 &h->GPx, &h->dZ})
     if (b->p) hipFree(b->p);
   if (h->info) hipFree(h->info);
   for (auto& ev : h->ev)
@@ -339,6 +512,12 @@ int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units) 
   HIPCHK(h, hipMemcpy(h->Y.p, yt.data(), sizeof(double) * yt.size(), hipMemcpyHostToDevice));
   h->n_units = n_units;
   h->factorized = false;
+  h->yy.assign(n_units, 0.0);
+  for (int u = 0; u < n_units; ++u) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < h->n; ++i) acc += y[i * n_units + u] * y[i * n_units + u];
+    h->yy[u] = acc;
+  }
   return GPRX_OK;
 }
 
@@ -350,21 +529,37 @@ static int objective_impl(gprx_handle h, int unit, const double* theta, const do
   for (int k = 0; k < h->ntheta; ++k)
     if (!std::isfinite(theta[k])) return fail(h, GPRX_EINVAL, "theta is not finite");
   const Theta t = decode_theta(h, theta);
-  if (h->m != 0) return fail(h, GPRX_EINVAL, "sparse (m > 0) path not built in this library version");
-  (void)z;
-  double lml = 0.0;
-  if ((rc = exact_factorize(h, unit, t, &lml))) return rc;
+  const bool sparse = h->m != 0;
+  double value = 0.0;  // LML (exact) or ELBO (sparse)
+  if (sparse) {
+    if ((rc = sgpr_factorize(h, unit, t, z, &value))) return rc;
+  } else {
+    if ((rc = exact_factorize(h, unit, t, &value))) return rc;
+  }
   const double lp = log_prior(h, t, mask);
-  if (loss) *loss = -(lml + lp);
+  if (loss) *loss = -(value + lp);
   if (grad) {
     std::vector<double> g(h->ntheta, 0.0);
-    if ((rc = exact_gradient(h, t, g.data()))) return rc;
+    double* gz = sparse ? grad + h->ntheta : nullptr;
+    if (sparse) {
+      if ((rc = sgpr_gradient(h, unit, t, g.data(), gz))) return rc;
+    } else {
+      if ((rc = exact_gradient(h, t, g.data()))) return rc;
+    }
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-    // priors and softplus chain rule; loss = -(LML + log prior)
+    // priors and softplus chain rule; loss = -(value + log prior)
     grad[0] = (mask & GPRX_TRAIN_VARIANCE) ? -(g[0] + ln_dlogpdf(t.variance)) * sigmoid(t.w_var) : 0.0;
     for (int k = 0; k < h->nlen; ++k)
       grad[1 + k] = (mask & GPRX_TRAIN_LENGTHSCALE) ? -(g[1 + k] + ln_dlogpdf(t.ls[k])) * sigmoid(t.w_len[k]) : 0.0;
     grad[1 + h->nlen] = (mask & GPRX_TRAIN_NOISE) ? -(g[1 + h->nlen] + ln_dlogpdf(t.noise)) * sigmoid(t.w_noise) : 0.0;
+    if (sparse) {
+      const int64_t nz = h->m * h->d;
+      if (mask & GPRX_TRAIN_Z) {
+        for (int64_t e = 0; e < nz; ++e) gz[e] = -gz[e];
+      } else {
+        for (int64_t e = 0; e < nz; ++e) gz[e] = 0.0;
+      }
+    }
   } else {
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
   }
@@ -412,15 +607,44 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   if ((rc = check_handle(h))) return rc;
   if (!h->factorized) return fail(h, GPRX_ESTATE, "gprx_predict before a successful gprx_factorize / gprx_objective");
   if (ns < 0 || (ns > 0 && (!xs_dev || !mean_dev || !var_dev))) return fail(h, GPRX_EINVAL, "null argument");
-  if (h->m != 0) return fail(h, GPRX_EINVAL, "sparse (m > 0) path not built in this library version");
+  hipStream_t st = h->stream;
+  const int rows_per_chunk = 256;
+  if (h->m != 0) {
+    // gpflow SGPR.predict_f: tmp1 = L^-1 Kus, tmp2 = LB^-1 tmp1, mean = tmp2^T c,
+    // var = v + colsum(tmp2^2) - colsum(tmp1^2) (+ s for predict_y)
+    const int mp = (int)h->mp, m = (int)h->m;
+    const int tile = (int)std::min<int64_t>(PRED_TILE, round_up(ns, NB));
+    if ((rc = ensure(h, h->Ks, sizeof(double) * (size_t)mp * tile))) return rc;
+    const int nchunks = (mp + rows_per_chunk - 1) / rows_per_chunk;
+    if ((rc = ensure(h, h->pred, sizeof(double) * (size_t)nchunks * tile))) return rc;
+    const double base = h->variance + (include_noise ? h->noise : 0.0);
+    const double* cvec = h->Bm.p + (size_t)mp * mp;
+    for (int64_t t0 = 0; t0 < ns; t0 += tile) {
+      const int ts = (int)std::min<int64_t>(tile, ns - t0);
+      const int tsp = (int)round_up(ts, NB);
+      KmatArgs ka{h->Z.p, xs_dev + t0 * h->d, h->invls.p, h->Ks.p, tile, m, ts, h->d, mp, tsp, h->variance, 0.0, 0, 0.0, 0};
+      HIPCHK(h, launch_kmat(st, h->kid, ka));
+      dim3 grid((ts + 255) / 256, nchunks);
+      HIPCHK(h, trsm_lower_left(st, h->Qm.p, mp, h->invDL.p, h->Ks.p, tile, mp, tsp));
+      hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, (const double*)nullptr, mp, ts, rows_per_chunk,
+                         h->pred.p);
+      hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, base, -1.0, 0, var_dev + t0);
+      HIPCHK(h, trsm_lower_left(st, h->Bm.p, mp, h->invDB.p, h->Ks.p, tile, mp, tsp));
+      hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, cvec, mp, ts, rows_per_chunk, h->pred.p);
+      hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, 0, mean_dev + t0);
+      hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, (const double*)nullptr, mp, ts, rows_per_chunk,
+                         h->pred.p);
+      hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, 1, var_dev + t0);
+    }
+    HIPCHK(h, hipGetLastError());
+    return GPRX_OK;
+  }
   const int np = (int)h->np;
   const int64_t ld = h->np;
   const int tile = (int)std::min<int64_t>(PRED_TILE, round_up(ns, NB));
   if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile))) return rc;
-  const int rows_per_chunk = 256;
   const int nchunks = (np + rows_per_chunk - 1) / rows_per_chunk;
   if ((rc = ensure(h, h->pred, sizeof(double) * (size_t)nchunks * tile))) return rc;
-  hipStream_t st = h->stream;
   const double base = h->variance + (include_noise ? h->noise : 0.0);
   for (int64_t t0 = 0; t0 < ns; t0 += tile) {
     const int ts = (int)std::min<int64_t>(tile, ns - t0);
@@ -429,11 +653,11 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
     HIPCHK(h, launch_kmat(st, h->kid, ka));
     dim3 grid((ts + 255) / 256, nchunks);
     hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, h->alpha.p, np, ts, rows_per_chunk, h->pred.p);
-    hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, mean_dev + t0);
+    hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, 0, mean_dev + t0);
     HIPCHK(h, trsm_lower_left(st, h->Kmat.p, ld, h->invD.p, h->Ks.p, tile, np, tsp));
     hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, (const double*)nullptr, np, ts, rows_per_chunk,
                        h->pred.p);
-    hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, base, -1.0, var_dev + t0);
+    hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, base, -1.0, 0, var_dev + t0);
   }
   HIPCHK(h, hipGetLastError());
   return GPRX_OK;
@@ -481,15 +705,15 @@ int gprx_memcpy_d2h(int device, void* dst_host, const void* src_dev, int64_t byt
 
 // ---- building blocks ----------------------------------------------------------------------------
 int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const double* b_dev, int64_t n2, int d,
-              const double* inv_ls_host, double variance, double diag_add, double* out_dev, int64_t ld, int64_t n1p, int64_t n2p,
+              const double* ls_host, double variance, double diag_add, double* out_dev, int64_t ld, int64_t n1p, int64_t n2p,
               int mode) {
-  if (!a_dev || !b_dev || !inv_ls_host || !out_dev) return fail(nullptr, GPRX_EINVAL, "null argument");
+  if (!a_dev || !b_dev || !ls_host || !out_dev) return fail(nullptr, GPRX_EINVAL, "null argument");
   if (n1p % NB || n2p % NB || ld % 2 || n1p < n1 || n2p < n2 || ld < n2p) return fail(nullptr, GPRX_EINVAL, "padded sizes must be multiples of 64");
   if (kernel_id < 0 || kernel_id > 4 || mode < 0 || mode > 2) return fail(nullptr, GPRX_EINVAL, "bad kernel id or mode");
   HIPCHK(nullptr, hipSetDevice(device));
   double* dinv = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dinv, sizeof(double) * d));
-  HIPCHK(nullptr, hipMemcpy(dinv, inv_ls_host, sizeof(double) * d, hipMemcpyHostToDevice));
+  HIPCHK(nullptr, hipMemcpy(dinv, ls_host, sizeof(double) * d, hipMemcpyHostToDevice));
   KmatArgs ka{a_dev, b_dev, dinv, out_dev, ld, (int)n1, (int)n2, d, (int)n1p, (int)n2p, variance, diag_add, mode, mode ? 1.0 : 0.0, 0};
   hipError_t e = launch_kmat(nullptr, kernel_id, ka);
   hipError_t e2 = hipDeviceSynchronize();

@@ -17,14 +17,18 @@ namespace gprx {
 struct TraceArgs {
   const double* a;       // (n1, d) row points (exact: X; sparse: Z)
   const double* b;       // (n2, d) column points
-  const double* inv_ls;  // d
+  const double* ls;      // d lengthscales
   const double* W;       // weights, row-major, ldw
   int64_t ldw;
-  const double* alpha;   // exact mode: W_ij = alpha_i alpha_j - W[i][j]; else null
+  const double* u;       // optional rank-1 term: w_ij = w_scale * W[i][j] + uv_scale * u[i] * v[j]
+  const double* v;       //   (exact GP: u = v = alpha, w_scale = -1, uv_scale = 1)
+  double w_scale, uv_scale;
   int n1, n2, d;
   double variance;
   int sym;               // 1: a == b, only tiles on/below the diagonal are visited, off-diagonal weights doubled
   double* partial;       // [grid][2 + d]: S_g, S_trace, S_len[k]
+  double* wh_out;        // optional (n1, n2) store of w * variance * h (feeds the dZ GEMM), leading dimension ldwh
+  int64_t ldwh;
   int tiles_n;
 };
 
@@ -54,9 +58,9 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
       const int k = k0 + kk;
       double va = 0.0, vb = 0.0;
       if (k < p.d) {
-        const double s = p.inv_ls[k];
-        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] * s;
-        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] * s;
+        const double s = p.ls[k];
+        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] / s;
+        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] / s;
       }
       sA[pt][kk] = va;
       sBt[kk][pt] = vb;
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
       const int j = j0 + 2 * cp + c;
       double w = 0.0;
       if (i < p.n1 && j < p.n2) {
-        w = p.W[(int64_t)i * p.ldw + j];
-        if (p.alpha) w = p.alpha[i] * p.alpha[j] - w;
+        w = p.w_scale * p.W[(int64_t)i * p.ldw + j];
+        if (p.u) w = __builtin_fma(p.uv_scale * p.u[i], p.v[j], w);
         if (p.sym) {
           if (j > i) w = 0.0;
           else if (j < i) w *= 2.0;
@@ -107,6 +111,14 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
       sg = __builtin_fma(w, g, sg);
       if (i == j) str += w;
       wh[it][c] = w * p.variance * h;
+    }
+    if (p.wh_out && i < p.n1) {
+      const int j = j0 + 2 * cp;
+      if (j + 1 < p.n2) {
+        *reinterpret_cast<d2*>(p.wh_out + (int64_t)i * p.ldwh + j) = d2{wh[it][0], wh[it][1]};
+      } else if (j < p.n2) {
+        p.wh_out[(int64_t)i * p.ldwh + j] = wh[it][0];
+      }
     }
   }
 
@@ -142,9 +154,30 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
     for (int kk = 0; kk < KM_DC; ++kk) block_sum_store(sk[kk], 2 + kk);
     __syncthreads();
     if (tid < KM_DC && k0 + tid < p.d)
-      out[2 + k0 + tid] = -(sRed[0][2 + tid] + sRed[1][2 + tid] + sRed[2][2 + tid] + sRed[3][2 + tid]) * p.inv_ls[k0 + tid];
+      out[2 + k0 + tid] = -(sRed[0][2 + tid] + sRed[1][2 + tid] + sRed[2][2 + tid] + sRed[3][2 + tid]) / p.ls[k0 + tid];
     __syncthreads();
   }
+}
+
+// dELBO/dZ of the sparse model, one workgroup per (inducing point i, dimension k):
+//   dZ[i][k] = ( sum_n WHP[i][n] (z_ik - x_nk) + 2 sum_j WHQ[i][j] (z_ik - z_jk) ) / l_k^2
+// with WHP = dELBO/dKuf * v h and WHQ = dELBO/dKuu * v h as stored by trace_kernel.  The differences
+// are formed explicitly: for kernels whose h is singular at r -> 0 (Matern-1/2, "Exponential") the
+// algebraically equal  z rowsum(WH) - WH X  cancels catastrophically on near-coincident points.
+__global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, const double* __restrict__ X, const double* __restrict__ WHP,
+                                                 int64_t ldp, const double* __restrict__ WHQ, int64_t ldq, const double* __restrict__ ls,
+                                                 int m, int n, int d, double* __restrict__ dZ) {
+  __shared__ double sred[4];
+  const int i = blockIdx.x / d, k = blockIdx.x % d;
+  const double z = Z[(int64_t)i * d + k];
+  double acc = 0.0;
+  for (int c = threadIdx.x; c < n; c += 256) acc = __builtin_fma(WHP[(int64_t)i * ldp + c], z - X[(int64_t)c * d + k], acc);
+  double accq = 0.0;
+  for (int c = threadIdx.x; c < m; c += 256) accq = __builtin_fma(WHQ[(int64_t)i * ldq + c], z - Z[(int64_t)c * d + k], accq);
+  acc = wave_sum(acc + 2.0 * accq);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dZ[(int64_t)i * d + k] = (sred[0] + sred[1] + sred[2] + sred[3]) / (ls[k] * ls[k]);
 }
 
 // out[e] = sum over workgroups of partial[wg][e]

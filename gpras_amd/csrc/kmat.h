@@ -68,7 +68,7 @@ __device__ __forceinline__ void corr_gh(double r2, double& g, double& h) {
 struct KmatArgs {
   const double* a;       // (n1, d)
   const double* b;       // (n2, d)
-  const double* inv_ls;  // d values, device
+  const double* ls;      // d lengthscales, device (coordinates are divided by them, as gpflow's scale())
   double* out;
   int64_t ld;
   int n1, n2, d;
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
       const int k = k0 + kk;
       double va = 0.0, vb = 0.0;
       if (k < p.d) {
-        const double s = p.inv_ls[k];
-        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] * s;
-        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] * s;
+        const double s = p.ls[k];
+        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] / s;
+        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] / s;
       }
       sA[pt][kk] = va;
       sBt[kk][pt] = vb;

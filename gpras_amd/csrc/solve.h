@@ -207,14 +207,14 @@ __global__ __launch_bounds__(256) void colreduce_partial(const double* __restric
   partial[(int64_t)blockIdx.y * ncols + t] = s0 + s1;
 }
 
-// out[t] = base + scale * sum_chunks partial[chunk][t]
+// out[t] = (accumulate ? out[t] : base) + scale * sum_chunks partial[chunk][t]
 __global__ __launch_bounds__(256) void colreduce_final(const double* __restrict__ partial, int nchunks, int ncols, double base, double scale,
-                                                       double* __restrict__ out) {
+                                                       int accumulate, double* __restrict__ out) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ncols) return;
   double s = 0.0;
   for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * ncols + t];
-  out[t] = base + scale * s;
+  out[t] = (accumulate ? out[t] : base) + scale * s;
 }
 
 }  // namespace gprx

@@ -125,11 +125,12 @@ int gprx_memcpy_d2h(int device, void* dst_host, const void* src_dev, int64_t byt
  * the NULL stream of `device` and synchronise before returning unless noted. */
 
 /* out[i, j] = variance * g(r(a_i, b_j)) + (i == j ? diag_add : 0)
- * a: (n1, d), b: (n2, d) device, inv_ls: d host values (1 / lengthscale per dimension).
- * mode 0: all of the (n1p, n2p) padded rectangle; mode 1: a == b, only tiles on or below the
- * diagonal are written (what the Cholesky reads).  Padding (i >= n1 or j >= n2): identity. */
+ * a: (n1, d), b: (n2, d) device, ls: d host values (lengthscale per dimension; inputs are divided by it).
+ * mode 0: all of the (n1p, n2p) padded rectangle, zero padding; mode 1: a == b, only tiles on or
+ * below the diagonal are written (what the Cholesky reads); mode 2: a == b, all tiles.  Modes 1
+ * and 2 pad (i >= n1 or j >= n2) with the identity. */
 int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const double* b_dev, int64_t n2, int d,
-              const double* inv_ls_host, double variance, double diag_add, double* out_dev, int64_t ld, int64_t n1p,
+              const double* ls_host, double variance, double diag_add, double* out_dev, int64_t ld, int64_t n1p,
               int64_t n2p, int mode);
 
 /* C = alpha * op(A) op(B) + beta * C;  ta/tb: 0 = as stored, 1 = transposed.  Supported:

@@ -80,7 +80,7 @@ def test_kmat_vs_oracle(lib, kernel, ard):
     ls = rng.uniform(0.5, 2.0, size=d) if ard else np.full(d, 0.8)
     n1p, n2p = 192, 256
     dA, dB, dO = DeviceBuffer.from_array(a), DeviceBuffer.from_array(b), DeviceBuffer(n1p * n2p * 8)
-    inv = np.ascontiguousarray(1.0 / ls)
+    inv = np.ascontiguousarray(ls, dtype=np.float64)
     check(lib.gprx_kmat(0, okn.KERNEL_IDS[kernel], dA.ptr, n1, dB.ptr, n2, d, ptr(inv), 1.7, 0.0, dO.ptr, n2p, n1p, n2p, 0))
     got = dO.to_array((n1p, n2p))
     ref = okn.kmat(kernel, a, b, 1.7, ls)
