@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark: exact-GP fits/sec (and predict points/sec) at N=4096, d=8, fp64 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one fit F1 of one cell at fixed hyperparameters: stationary-kernel matrix build
+(lower tiles) + blocked fp64-MFMA Cholesky with y carried as an extra row + backward solve for alpha +
+log marginal likelihood returned to the host -- BASELINE.json configs[1] ("Single cell, N=4096 d=8
+RBF fp64 on 1 MI355X: HIP kernel build + blocked MFMA Cholesky").  Inputs are resident in HBM when the
+timed region starts.  With N > 1 ranks every rank fits its own cells (independent units, SURVEY.md
+section 8e: no data-path collective) and one RCCL all_gather collects the results at the end; the
+reported value is all ranks' fits divided by the slowest rank's time ("weak" scaling).
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline      -- the dominant kernel (the Cholesky trailing-update GEMM) against the fp64 MFMA peak,
+                   per-launch durations taken with HIP events on the launch stream in an instrumented
+                   pass over the same workload;
+  cpu_baseline  -- the numpy/scipy oracle (a restatement, "port": the reference cannot be imported here)
+                   timed on this box's host cores on a bounded sample;
+  extra         -- F2 (objective + gradient), F3 (50 L-BFGS-B iterations, Matern-5/2 ARD) and predict rates.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_TRAIN, DIM, N_TEST = 4096, 8, 100_000
+FP64_MFMA_PEAK_TFLOPS = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz: half the f32 matrix rate of MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true", help="skip F2/F3/predict/cpu legs (profiling runs)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or "RANK" in os.environ
+    torch = dist = None
+    if distributed:
+        # torch first: libgprx.so then binds to the HIP runtime torch already loaded (same soname)
+        import torch  # noqa: PLC0415
+        import torch.distributed as dist  # noqa: PLC0415
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from gpras_amd import _build, _lib
+    from gpras_amd._lib import DeviceBuffer, check, ptr
+    from gpras_amd.synth import make_regression
+
+    if rank == 0:
+        _build.build()
+    if distributed:
+        dist.barrier()
+    lib = _lib.load()
+    device = local_rank if distributed else 0
+
+    # ---- workload: one cell per rank, seeds 1000 * config + unit ----
+    x, y, xs = make_regression(N_TRAIN, DIM, n_outputs=1, n_test=N_TEST, config=2, unit=rank)
+    h = C.c_void_p()
+    check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    # reference initial values: variance 1, lengthscale mean|x|, noise 1 (gpr.py:289, :298)
+    from gpras_amd.model import NOISE_LOWER, softplus_inv
+
+    theta = np.ascontiguousarray([softplus_inv(1.0), softplus_inv(np.mean(np.abs(x))), softplus_inv(1.0 - NOISE_LOWER)], dtype=np.float64)
+    mask = 7
+    loss = C.c_double()
+
+    def sync_all():
+        check(lib.gprx_synchronize(h), h)
+        if distributed:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def fit_step():
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, mask, C.byref(loss)), h)
+
+    for _ in range(args.warmup):
+        fit_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fit_step()
+    if distributed:
+        # the single collective of the job: gather every rank's result over RCCL
+        mine = torch.tensor([loss.value], dtype=torch.float64, device=f"cuda:{local_rank}")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    fits_per_s = world * args.steps / elapsed
+
+    result = {
+        "metric": "gp_fits_per_sec",
+        "value": fits_per_s,
+        "unit": "fits/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: one cell per GPU, exact GP N=4096 d=8 RBF, fit F1 = kernel build + blocked fp64-MFMA Cholesky + alpha + LML",
+            "n_train": N_TRAIN,
+            "d": DIM,
+            "kernel": "RBF",
+            "cells_per_gpu_per_step": 1,
+            "parallelism": f"independent cells x {world} GPU, one RCCL all_gather at the end",
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: instrumented pass, HIP events around every launch ----
+        check(lib.gprx_set_profiling(h, 1), h)
+        prof = (C.c_double * 5)()
+        acc = np.zeros(5)
+        reps = 3
+        for _ in range(reps):
+            fit_step()
+            lib.gprx_last_profile(h, prof)
+            acc += np.array(list(prof))
+        check(lib.gprx_set_profiling(h, 0), h)
+        gemm_ms, gemm_launches, gemm_flops, panel_ms, panel_launches = acc / reps
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "gprx::gemm_f64_kernel<0,1,*> (Cholesky trailing update, A22 -= L21 L21^T)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches_per_fit": gemm_launches,
+            "avg_launch_us": 1e3 * gemm_ms / gemm_launches,
+            "algorithmic_flops_per_fit": gemm_flops,
+            "panel_kernel_avg_us": 1e3 * panel_ms / panel_launches,
+        }
+        ms = (C.c_double * 4)()
+        lib.gprx_last_timings(h, ms)
+        kmat_bytes = 8.0 * (N_TRAIN * (N_TRAIN + 64) / 2) + 8.0 * N_TRAIN * DIM
+        result["stages_ms"] = {"kernel_build": ms[0], "cholesky": ms[1], "solves": ms[2]}
+        result["kernel_build_hbm"] = {"GBps": kmat_bytes / (ms[0] * 1e-3) / 1e9, "frac_of_8TBps": kmat_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if rank == 0 and not args.no_extras:
+        extra = {}
+        # F2: objective + gradient
+        grad = np.zeros(3)
+        check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
+        t1 = time.perf_counter()
+        k2 = max(3, args.steps // 4)
+        for _ in range(k2):
+            check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
+        extra["F2_objective_grad_evals_per_s"] = k2 / (time.perf_counter() - t1)
+        # predict: mean + variance at 100k points, inputs and outputs resident in HBM
+        fit_step()
+        dxs = DeviceBuffer.from_array(xs, device)
+        dmean, dvar = DeviceBuffer(8 * N_TEST, device), DeviceBuffer(8 * N_TEST, device)
+        check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
+        check(lib.gprx_synchronize(h), h)
+        t1 = time.perf_counter()
+        check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
+        check(lib.gprx_synchronize(h), h)
+        tp = time.perf_counter() - t1
+        extra["predict_points_per_s"] = N_TEST / tp
+        extra["predict_tflops"] = (N_TRAIN**2 * N_TEST + 2.0 * N_TRAIN * N_TEST) / tp / 1e12
+        extra["predict_n_test"] = N_TEST
+        gpu_mean = dmean.to_array((N_TEST,))[:2000]
+        gpu_var = dvar.to_array((N_TEST,))[:2000]
+        # F3: BASELINE configs[2] -- Matern-5/2 ARD, 50 L-BFGS-B iterations on the exact LML
+        from gpras_amd.gpr import GPRAS
+
+        g3 = GPRAS("Matern52", device=device)
+        t1 = time.perf_counter()
+        g3.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
+        t3 = time.perf_counter() - t1
+        extra["F3_lbfgs50_matern52_ard_seconds"] = t3
+        extra["F3_evaluations"] = g3.models[0].n_evals
+        extra["F3_fits_per_s"] = 1.0 / t3
+        result["extra"] = extra
+
+        # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----
+        from oracle import exact as oex
+
+        cores = os.cpu_count() or 1
+        try:
+            from threadpoolctl import threadpool_info
+
+            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            blas_threads = cores
+        v0, l0, s0 = 1.0, float(np.mean(np.abs(x))), 1.0
+        best = np.inf
+        cpu_lml = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            cpu_lml = oex.lml("RBF", x, y[:, 0], v0, l0, s0)
+            best = min(best, time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        cm, cv = oex.predict("RBF", x, y[:, 0], v0, l0, s0, xs[:2000])
+        tcp = time.perf_counter() - t1
+        # parity of the benchmarked step itself, at full size
+        gpu_loss_check = -(cpu_lml + sum(-np.log(u) - 0.5 * np.log(2 * np.pi) - 0.5 * np.log(u) ** 2 for u in (v0, l0, s0)))
+        fit_step()
+        result["cpu_baseline"] = {
+            "value": 1.0 / best,
+            "unit": "fits/s",
+            "cores": int(min(cores, blas_threads)),
+            "kind": "port",
+            "sample": f"3 F1 fits (best of 3) at N={N_TRAIN} d={DIM} with oracle/exact.py (numpy + scipy LAPACK); predict on 2000 of the {N_TEST} points",
+            "predict_points_per_s": 2000 / tcp,
+            "host_cpu_count": cores,
+        }
+        result["parity_at_bench_size"] = {
+            "loss_rel_err_vs_oracle": abs(loss.value - gpu_loss_check) / abs(gpu_loss_check),
+            "predict_mean_rel_err": float(np.max(np.abs(gpu_mean - cm)) / np.max(np.abs(cm))),
+            "predict_var_rel_err": float(np.max(np.abs(gpu_var - cv) / cv)),
+        }
+
+    lib.gprx_destroy(h)
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "gprx_predict": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_predict_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_last_timings": (C.c_int, [_vp, _dp]),
+    "gprx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "gprx_last_profile": (C.c_int, [_vp, _dp]),
     "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "gprx_dev_malloc": (C.c_int, [C.c_int, _i64, C.POINTER(_vp)]),
     "gprx_dev_free": (C.c_int, [C.c_int, _vp]),

@@ -53,6 +53,9 @@ struct gprx_ctx {
   double variance = 1.0, noise = 1.0;
   std::vector<double> ls;
   double timings[4] = {0, 0, 0, 0};
+  bool profiling = false;
+  PotrfProfile prof;
+  double prof_out[6] = {0, 0, 0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -180,7 +183,8 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
                      (int)h->n, np, NB);
   HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
-  HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info));
+  if (h->profiling) h->prof.reset();
+  HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->profiling ? &h->prof : nullptr));
   HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
   hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
@@ -192,6 +196,25 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
   HIPCHK(h, hipMemcpyAsync(red, h->red.p, sizeof(red), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  if (h->profiling) {
+    double gemm_ms = 0.0, gemm_flops = 0.0, panel_ms = 0.0;
+    for (auto& mk : h->prof.gemm_marks) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
+      gemm_ms += ms;
+      gemm_flops += mk.second;
+    }
+    for (auto idx : h->prof.panel_marks) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, h->prof.pool[idx], h->prof.pool[idx + 1]);
+      panel_ms += ms;
+    }
+    h->prof_out[0] = gemm_ms;
+    h->prof_out[1] = (double)h->prof.gemm_marks.size();
+    h->prof_out[2] = gemm_flops;
+    h->prof_out[3] = panel_ms;
+    h->prof_out[4] = (double)h->prof.panel_marks.size();
+  }
   if (info != 0) {
     h->factorized = false;
     char msg[128];
@@ -583,6 +606,18 @@ int gprx_factorize(gprx_handle h, int unit, const double* theta, const double* z
 int gprx_last_timings(gprx_handle h, double* ms4) {
   if (!h || !ms4) return fail(h, GPRX_EINVAL, "null argument");
   for (int s = 0; s < 4; ++s) ms4[s] = h->timings[s];
+  return GPRX_OK;
+}
+
+int gprx_set_profiling(gprx_handle h, int enabled) {
+  if (!h) return fail(h, GPRX_EINVAL, "null handle");
+  h->profiling = enabled != 0;
+  return GPRX_OK;
+}
+
+int gprx_last_profile(gprx_handle h, double* out5) {
+  if (!h || !out5) return fail(h, GPRX_EINVAL, "null argument");
+  for (int i = 0; i < 5; ++i) out5[i] = h->prof_out[i];
   return GPRX_OK;
 }
 

@@ -13,6 +13,9 @@
 //      triangular solves).
 //   2. gemm_f64 (NT, C_LOWER, alpha = -1, beta = 1) -- trailing update A22 -= L21 L21^T on MFMA.
 #pragma once
+#include <utility>
+#include <vector>
+
 #include "gemm_f64.h"
 #include "gprx_common.h"
 
@@ -159,20 +162,57 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   }
 }
 
+// Optional per-launch timing of the two kernels of the factorisation (HIP events on the launch stream).
+struct PotrfProfile {
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<std::pair<size_t, double>> gemm_marks;  // (index of start event, algorithmic flops of the launch)
+  std::vector<size_t> panel_marks;
+  hipEvent_t next() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  void reset() {
+    used = 0;
+    gemm_marks.clear();
+    panel_marks.clear();
+  }
+  ~PotrfProfile() {
+    for (auto e : pool) hipEventDestroy(e);
+  }
+};
+
 // Factor the (np x np) matrix in place; `extra` rows below it are carried as right-hand sides.
 // inv_diag: np/64 blocks of 64 x 64.  info (device int) must be zeroed by the caller.
-inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info) {
+inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
+                              PotrfProfile* prof = nullptr) {
   for (int c = 0; c < np; c += NB) {
     const int rows_below = np - c - NB + extra;
     const int nchunks = (rows_below + PANEL_ROWS - 1) / PANEL_ROWS;
     double* Acc = A + (int64_t)c * lda + c;
+    if (prof) {
+      prof->panel_marks.push_back(prof->used);
+      hipEventRecord(prof->next(), st);
+    }
     hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
                        inv_diag + (int64_t)(c / NB) * NB * NB, info, c);
+    if (prof) hipEventRecord(prof->next(), st);
     const int ncols = np - c - NB;
     if (ncols > 0) {
       double* L21 = A + (int64_t)(c + NB) * lda + c;
       double* A22 = A + (int64_t)(c + NB) * lda + (c + NB);
+      if (prof) {
+        // algorithmic flops: 2 K per updated element of the lower trapezoid (diagonal included)
+        const double elems = 0.5 * (double)ncols * (ncols + 1) + (double)extra * ncols;
+        prof->gemm_marks.push_back({prof->used, 2.0 * NB * elems});
+        hipEventRecord(prof->next(), st);
+      }
       hipError_t e = launch_gemm(st, 0, 1, rows_below, ncols, NB, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER);
+      if (prof) hipEventRecord(prof->next(), st);
       if (e != hipSuccess) return e;
     }
   }

@@ -1,0 +1,96 @@
+"""Handle-level wrapper of the C ABI: one `Engine` = one gprx handle = one training set on one GPU.
+
+The engine is the only backend the package ships.  It raises (never falls back) when
+libgprx.so is missing or a device call fails.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KERNEL_IDS, as_f64, check, ptr
+
+
+class Engine:
+    """Owns the device copy of ``x (N, d)``, ``y (N, K)`` and all factorisation workspaces.
+
+    ``n_inducing = 0`` selects the exact GP; otherwise the sparse model with that many inducing points
+    (``SGPR`` at ``/root/reference/gpras/gpr.py:299``).
+    """
+
+    def __init__(self, kernel: str, x, y, n_inducing: int = 0, ard: bool = False, device: int = 0):
+        self._lib = _lib.load()
+        self.kernel = kernel
+        kernel_id = KERNEL_IDS[kernel]  # KeyError for unknown names, as gpr.py:230
+        x = as_f64(x)
+        y = as_f64(y)
+        if x.ndim != 2 or y.ndim != 2 or x.shape[0] != y.shape[0]:
+            raise ValueError("x must be (N, d) and y (N, K) with matching N")
+        self.x = x  # host copy (the multi-start driver samples Z inside its bounding box)
+        self.n, self.d = x.shape
+        self.n_units = y.shape[1]
+        self.m = int(n_inducing or 0)
+        self.ard = bool(ard)
+        self.n_len = self.d if self.ard else 1
+        self.n_theta = 2 + self.n_len
+        self.device = device
+        self._h = C.c_void_p()
+        check(self._lib.gprx_create(device, self.n, self.d, self.m, kernel_id, int(self.ard), C.byref(self._h)))
+        check(self._lib.gprx_set_data(self._h, ptr(x), ptr(y), self.n_units), self._h)
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gprx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- evaluations -----------------------------------------------------------------------------
+    def _z_ptr(self, z):
+        if self.m == 0:
+            return None, None
+        z = as_f64(z)
+        if z.shape != (self.m, self.d):
+            raise ValueError(f"Z must have shape {(self.m, self.d)}, got {z.shape}")
+        return z, ptr(z)
+
+    def objective(self, unit: int, theta, z, mask: int, want_grad: bool = True):
+        """``training_loss`` and (optionally) its gradient ``[d theta | d Z]`` for one output unit."""
+        theta = as_f64(theta)
+        if theta.shape != (self.n_theta,):
+            raise ValueError(f"theta must have {self.n_theta} entries")
+        zk, zp = self._z_ptr(z)
+        loss = C.c_double()
+        if want_grad:
+            grad = np.zeros(self.n_theta + self.m * self.d)
+            check(self._lib.gprx_objective(self._h, unit, ptr(theta), zp, mask, C.byref(loss), ptr(grad)), self._h)
+            return loss.value, grad
+        check(self._lib.gprx_factorize(self._h, unit, ptr(theta), zp, mask, C.byref(loss)), self._h)
+        return loss.value, None
+
+    def predict(self, xs, include_noise: bool = True):
+        """Mean and variance at ``xs`` for the unit factorised by the last ``objective`` call."""
+        xs = as_f64(xs)
+        if xs.ndim != 2 or xs.shape[1] != self.d:
+            raise ValueError(f"x must be (N*, {self.d})")
+        mean = np.empty(xs.shape[0])
+        var = np.empty(xs.shape[0])
+        check(self._lib.gprx_predict(self._h, ptr(xs), xs.shape[0], ptr(mean), ptr(var), int(include_noise)), self._h)
+        return mean, var
+
+    def timings(self):
+        ms = (C.c_double * 4)()
+        self._lib.gprx_last_timings(self._h, ms)
+        return {"kernel_build_ms": ms[0], "cholesky_ms": ms[1], "solves_ms": ms[2], "gradient_ms": ms[3]}
+
+    @property
+    def handle(self):
+        return self._h

@@ -1,0 +1,156 @@
+"""Methods for GPR training, tuning, and prediction -- MI355X-native drop-in for ``gpras/gpr.py``.
+
+Keeps the public surface of the reference class (``/root/reference/gpras/gpr.py:217-384``):
+``GPRAS(kernel)``, ``fit``, ``predict``, ``to_file``, ``from_file``, attributes ``kernel_str``, ``x``, ``y``,
+``models`` (with ``models[i].inducing_variable.Z``), and the registries ``KERNEL_FACTORY`` /
+``OPTIMIZERS`` plus the three ``Literal`` types that ``production/analysis/data_models.py:12`` imports.
+
+All arithmetic runs in ``libgprx.so`` (hand-written HIP for gfx950) through ``gpras_amd.engine.Engine``;
+there is no CPU path.  Extensions beyond the reference: ``n_inducing=None`` fits the exact GP
+(``Z = X``) and ``ard=True`` gives one lengthscale per feature.
+"""
+
+from __future__ import annotations
+
+import pickle
+from pathlib import Path
+from typing import Any, Literal
+
+import numpy as np
+from numpy.typing import NDArray
+
+from ._lib import KERNEL_IDS
+from .engine import Engine
+from .model import GPModel
+from .optimizers import OPTIMIZERS
+
+# names that the reference maps to gpflow kernel classes (gpr.py:21-37).  Linear / Polynomial / Periodic
+# are listed there but cannot be constructed with (variance=, lengthscales=) at gpr.py:298 ("currently
+# not working" in the reference's own comments); they raise here too, at construction time.
+KERNEL_FACTORY = {name: name for name in KERNEL_IDS}
+_REFERENCE_ONLY = ("Linear", "Polynomial", "Periodic")
+
+KernelType = Literal["Matern12", "Matern32", "Matern52", "RBF", "Linear", "Polynomial", "Periodic", "Exponential"]
+OptimizerType = Literal["two-stage", "adam", "L-BFGS-B", "stochastic", "diffential_evolution"]
+InductionInitializerType = Literal["kmeans", "grid"]
+
+FILE_FORMAT = "gpras_amd-1"
+
+
+class GPRAS:
+    """Gaussian Process Regression for HEC-RAS model upskilling and emulation."""
+
+    def __init__(self, kernel: KernelType, device: int = 0) -> None:
+        self.kernel_str = kernel
+        if kernel in _REFERENCE_ONLY:
+            raise NotImplementedError(
+                f"kernel {kernel!r} is listed by the reference but cannot be built by its own fit() "
+                "(gpr.py:26-27, :298); only the stationary kernels are implemented"
+            )
+        self.kernel = KERNEL_FACTORY[kernel]  # KeyError for unknown names, as the reference
+        self.device = device
+        self.models: list[GPModel] = []
+        self.x: NDArray[Any] | None = None
+        self.y: NDArray[Any] | None = None
+        self.engine: Engine | None = None
+        self.ard = False
+
+    def fit(
+        self,
+        x: NDArray[Any],
+        y: NDArray[Any],
+        n_inducing: int | None,
+        inducing_initializer: InductionInitializerType = "kmeans",
+        optimization_method: OptimizerType = "two-stage",
+        ard: bool = False,
+        **opt_kwargs: Any,
+    ) -> None:
+        """Fit one GP per column of ``y`` (gpr.py:237-275)."""
+        self.x = x.astype(np.float64)
+        self.y = y.astype(np.float64)
+        self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard)
+        opt = OPTIMIZERS[optimization_method]
+        for _, model in enumerate(self.models):
+            opt(model, **opt_kwargs)
+
+    def _init_models(
+        self,
+        x: NDArray[Any],
+        y: NDArray[Any],
+        n_inducing: int | None,
+        inducing_initializer: InductionInitializerType = "kmeans",
+        ard: bool = False,
+    ) -> None:
+        """Create one model per spatial mode using base model settings (gpr.py:277-308)."""
+        inducing = None if n_inducing is None else self._create_inducing(x, n_inducing, inducing_initializer)
+        ini_length = np.mean(abs(x))
+        self.ard = bool(ard)
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = Engine(self.kernel_str, x, y, 0 if inducing is None else inducing.shape[0], ard=self.ard, device=self.device)
+        # variance 1, lengthscale mean|x| (gpr.py:289, :298); Gaussian likelihood variance 1.0 (gpflow default)
+        self.models = [GPModel(self.engine, i, inducing, 1.0, ini_length, 1.0) for i in range(y.shape[1])]
+
+    def _create_inducing(self, x: NDArray[Any], n_inducing: int, method: InductionInitializerType) -> NDArray[Any]:
+        """Create an array representing locations in dataspace (gpr.py:310-320)."""
+        if method == "kmeans":
+            from sklearn.cluster import KMeans
+
+            km = KMeans(n_clusters=n_inducing, random_state=0, n_init="auto")
+            km.fit(x)
+            return np.ascontiguousarray(km.cluster_centers_.astype(np.float64))
+        elif method == "grid":
+            inducing_variable = np.c_[np.linspace(x[:, 0].min(), x[:, 0].max(), n_inducing)]
+            for j in range(1, x.shape[1]):
+                inducing_variable = np.c_[inducing_variable, np.linspace(x[:, j].min(), x[:, j].max(), n_inducing)]
+            return np.ascontiguousarray(inducing_variable)
+        raise ValueError(f"unknown inducing initializer {method!r}")  # the reference silently returns None here
+
+    def predict(self, x: NDArray[Any]) -> tuple[NDArray[Any], NDArray[Any]]:
+        """Predictive mean and observation variance, each (n_samples, n_outputs) (gpr.py:322-342)."""
+        x = x.astype(np.float64)
+        means = []
+        variances = []
+        for model in self.models:
+            pred = model.predict_y(x)
+            means.append(pred[0])
+            variances.append(pred[1])
+        return np.concatenate(means, axis=1), np.concatenate(variances, axis=1)
+
+    def to_file(self, json_path: str | Path, model_dir: str | Path | None = None) -> None:
+        """Serialize the trained model (gpr.py:344-366).
+
+        Same dictionary layout as the reference -- ``kernel``, ``data{x, y}``, ``n_inducing``, ``models`` with
+        gpflow's parameter-dict keys -- but the values are plain numpy arrays, so the file loads without
+        gpflow.  ``model_dir`` is accepted and ignored, as in the reference.
+        """
+        z0 = self.models[0].Z
+        d = {
+            "format": FILE_FORMAT,
+            "kernel": self.kernel_str,
+            "data": {"x": self.x, "y": self.y},
+            "n_inducing": None if z0 is None else z0.shape[0],
+            "ard": self.ard,
+            "models": [m.parameter_dict() for m in self.models],
+        }
+        with open(json_path, mode="wb") as f:
+            pickle.dump(d, f)
+
+    @classmethod
+    def from_file(cls, json_path: str | Path, device: int = 0) -> "GPRAS":
+        """Load a model written by ``to_file`` (gpr.py:368-384): re-initialise with the cheap ``"grid"``
+        inducing points, then assign every saved parameter."""
+        with open(json_path, mode="rb") as f:
+            d = pickle.load(f)
+        if d.get("format") != FILE_FORMAT:
+            raise ValueError(
+                "not a gpras_amd model file; files written by the reference hold pickled gpflow Parameter "
+                "objects and can only be read where gpflow is installed"
+            )
+        inst = cls(d["kernel"], device=device)
+        inst.x = d["data"]["x"]
+        inst.y = d["data"]["y"]
+        inst._init_models(inst.x, inst.y, d["n_inducing"], "grid", d.get("ard", False))
+        for ind, params in enumerate(d["models"]):
+            inst.models[ind].multiple_assign(params)
+        return inst

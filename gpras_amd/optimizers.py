@@ -1,0 +1,157 @@
+"""Optimiser drivers with the names, signatures and quirks of ``/root/reference/gpras/gpr.py:44-214``.
+
+Each driver works on a ``gpras_amd.model.GPModel``; one loss/gradient evaluation is one call into the
+HIP engine.  Behaviour kept on purpose (SURVEY.md section 8a, quirk list):
+
+1. ``stochastic`` never records ``best_loss``: the last start wins; its generator is unseeded; it replaces
+   Z by a plain array, which freezes Z (gpr.py:86-109).
+2. Stage 1 of ``two-stage`` / ``three-stage`` trains Z only, so its loss carries no prior term.
+3. ``tol = 10e-6`` (that is 1e-5) and patience 50 in Adam's early stop.
+4. ``adam`` / ``L-BFGS-B`` / ``adadelta`` have no default ``max_iter``.
+5. ``three-stage`` and ``adadelta`` are registered although absent from ``OptimizerType``; the key
+   ``"diffential_evolution"`` is misspelled in the reference and that spelling is the public one.
+6. The differential-evolution objective evaluates the loss twice per call and prints it.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+from scipy.optimize import differential_evolution, minimize
+
+
+def _optimize_adam(model, max_iter: int) -> None:
+    """Keras ``Adam()`` defaults on the trainable variables, fresh state per call (gpr.py:147-173)."""
+    lr, beta1, beta2, eps = 1e-3, 0.9, 0.999, 1e-7
+    x = model.get_vector()
+    m = np.zeros_like(x)
+    v = np.zeros_like(x)
+    best = np.inf
+    count = 0
+    tol = 10e-6
+    patience = 50
+    for t in range(1, int(max_iter) + 1):
+        loss, grad = model.loss_and_grad()
+        m = beta1 * m + (1.0 - beta1) * grad
+        v = beta2 * v + (1.0 - beta2) * grad * grad
+        alpha = lr * np.sqrt(1.0 - beta2**t) / (1.0 - beta1**t)
+        x = x - alpha * m / (np.sqrt(v) + eps)
+        model.set_vector(x)
+        if ((best - loss) / abs(loss)) > tol:
+            best = loss
+            count = 0
+        else:
+            count += 1
+            if count > patience:
+                break
+
+
+def _optimize_adadelta(model, max_iter: int) -> Any:
+    """Keras ``Adadelta()`` defaults, exactly ``max_iter`` steps (gpr.py:176-192).  Returns the last loss."""
+    lr, rho, eps = 1e-3, 0.95, 1e-7
+    x = model.get_vector()
+    acc_grad = np.zeros_like(x)
+    acc_delta = np.zeros_like(x)
+    loss = None
+    for _ in range(int(max_iter)):
+        loss, grad = model.loss_and_grad()
+        acc_grad = rho * acc_grad + (1.0 - rho) * grad * grad
+        delta = -np.sqrt(acc_delta + eps) * grad / np.sqrt(acc_grad + eps)
+        acc_delta = rho * acc_delta + (1.0 - rho) * delta * delta
+        x = x + lr * delta
+        model.set_vector(x)
+    return loss
+
+
+def _optimize_bfgs(model, max_iter: int) -> Any:
+    """``gpflow.optimizers.Scipy().minimize(..., method="L-BFGS-B", options={"maxiter": max_iter})`` (gpr.py:195-203)."""
+
+    def fun(vec):
+        model.set_vector(vec)
+        return model.loss_and_grad()
+
+    res = minimize(fun, model.get_vector(), jac=True, method="L-BFGS-B", options={"maxiter": int(max_iter)})
+    model.set_vector(res.x)
+    return res
+
+
+def _optimize_two_stage(model, max_iter: int = 100) -> Any:
+    """Z first, then the hyperparameters, both with Adam (gpr.py:112-127)."""
+    model.set_all_trainable(False)
+    model.set_trainable(Z=True)
+    _optimize_adam(model, max_iter)
+    model.set_all_trainable(True)
+    model.set_trainable(Z=False)
+    _optimize_adam(model, max_iter)
+    model.set_trainable(Z=True)
+    return model.training_loss()
+
+
+def _optimize_three_stage(model, max_iter: int = 100) -> None:
+    """Adam on Z, L-BFGS-B on the hyperparameters, L-BFGS-B on everything (gpr.py:130-144)."""
+    model.set_all_trainable(False)
+    model.set_trainable(Z=True)
+    _optimize_adam(model, max_iter)
+    model.set_all_trainable(True)
+    model.set_trainable(Z=False)
+    _optimize_bfgs(model, max_iter)
+    model.set_trainable(Z=True)
+    _optimize_bfgs(model, max_iter)
+
+
+def _optimize_multi_start(model, n_starts: int = 40, iter_initial: int = 20, iter_final: int = 1000, rng=None) -> None:
+    """Random restarts + L-BFGS-B polish (gpr.py:73-109).  ``rng`` is a test hook; the reference's is unseeded."""
+    np.random.seed(1)  # gpr.py:76 -- has no effect on default_rng(), kept for fidelity
+    rng = np.random.default_rng() if rng is None else rng
+    x = model.backend_x()
+    mins, maxs = x.min(axis=0), x.max(axis=0)
+    z_shape = (model.Z.shape[0], x.shape[1])
+    best_params = None
+    for _ in range(int(n_starts)):
+        model.assign(variance=10 ** rng.uniform(-1, 1))
+        model.assign(lengthscales=10 ** rng.uniform(-1, 1))
+        model.assign(noise=10 ** rng.uniform(-3, 0))
+        model.Z = rng.uniform(mins, maxs, size=z_shape)
+        model.set_trainable(Z=False)  # gpr.py:91 swaps the Parameter for an ndarray: Z is no longer trainable
+        _optimize_adam(model, iter_initial)
+        model.training_loss()
+        # gpr.py:96 never assigns best_loss, so every start overwrites best_params
+        best_params = [model.variance, model.lengthscales, model.noise, model.Z.copy()]
+    model.assign(variance=best_params[0], lengthscales=best_params[1], noise=best_params[2])
+    model.Z = best_params[3]
+    _optimize_bfgs(model, iter_final)
+
+
+def _optimize_differential_evolutions(model, popsize: int = 15, max_iter: int = 500, seed=None, adam_iter: int = 3000, verbose=True) -> Any:
+    """Adam on Z, then scipy differential evolution over log10 of the three hyperparameters (gpr.py:44-70).
+
+    Every hyperparameter is frozen while DE runs, so the objective is ``-ELBO`` without priors.
+    ``seed``, ``adam_iter`` and ``verbose`` are additions (the reference prints every objective value).
+    """
+    model.set_all_trainable(False)
+    model.set_trainable(Z=True)
+    _optimize_adam(model, adam_iter)
+    param_bounds = [(-1, 1), (-1, 1), (-3, 0)]
+
+    def objective(params):
+        model.assign(variance=10 ** params[0], lengthscales=10 ** params[1], noise=10 ** params[2])
+        value = model.training_loss()
+        if verbose:
+            print(value)
+        return model.training_loss()
+
+    result = differential_evolution(objective, param_bounds, popsize=popsize, maxiter=max_iter, seed=seed)
+    model.assign(variance=10 ** result.x[0], lengthscales=10 ** result.x[1], noise=10 ** result.x[2])
+    return result
+
+
+OPTIMIZERS: dict[str, Any] = {
+    "two-stage": _optimize_two_stage,
+    "three-stage": _optimize_three_stage,
+    "adam": _optimize_adam,
+    "adadelta": _optimize_adadelta,
+    "L-BFGS-B": _optimize_bfgs,
+    "stochastic": _optimize_multi_start,
+    "diffential_evolution": _optimize_differential_evolutions,
+}

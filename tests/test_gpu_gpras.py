@@ -1,0 +1,80 @@
+"""End-to-end GPU tests of the drop-in class: GPRAS.fit / predict / to_file / from_file on the HIP
+engine against the oracle's CPU restatement of the same driver (same seeds, same inputs)."""
+
+import numpy as np
+import pytest
+
+from gpras_amd.gpr import GPRAS
+from gpras_amd.synth import make_hydrograph_features, make_regression
+from oracle import gpras_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_fit_predict_roundtrip(tmp_path):
+    """BASELINE config 1: single cell, N=256 d=4 RBF, fit + predict on synthetic hydrograph features."""
+    x, y = make_hydrograph_features(256, 4, n_outputs=2, config=1, unit=0)
+    xs = x[::5] + 0.01
+    g = GPRAS("RBF")
+    g.fit(x, y, n_inducing=24, inducing_initializer="kmeans", optimization_method="two-stage", max_iter=15)
+    ref = gpras_oracle.GPRASOracle("RBF")
+    ref.fit(x, y, n_inducing=24, inducing_initializer="kmeans", optimization_method="two-stage", max_iter=15)
+    for a, b in zip(g.models, ref.models):
+        assert a.variance == pytest.approx(b.variance, rel=1e-8)
+        assert a.lengthscales == pytest.approx(b.lengthscales, rel=1e-8)
+        assert a.noise == pytest.approx(b.noise, rel=1e-8)
+        assert np.allclose(a.inducing_variable.Z, b.Z, rtol=1e-8, atol=1e-10)
+    mean, var = g.predict(xs)
+    rmean, rvar = ref.predict(xs)
+    assert mean.shape == (xs.shape[0], 2) and var.shape == mean.shape
+    assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean))
+    assert np.max(np.abs(var - rvar) / rvar) <= 1e-8
+    path = tmp_path / "model.json"
+    g.to_file(path)
+    g2 = GPRAS.from_file(path)
+    mean2, var2 = g2.predict(xs)
+    assert np.array_equal(mean, mean2) and np.array_equal(var, var2)
+
+
+@pytest.mark.parametrize("kernel", ["Matern52", "Exponential"])
+def test_lbfgs_reaches_the_same_optimum(kernel):
+    x, y, xs = make_regression(400, 4, n_outputs=1, n_test=50, config=4, unit=1)
+    g = GPRAS(kernel)
+    g.fit(x, y, n_inducing=30, optimization_method="L-BFGS-B", max_iter=25)
+    ref = gpras_oracle.GPRASOracle(kernel)
+    ref.fit(x, y, n_inducing=30, optimization_method="L-BFGS-B", max_iter=25)
+    # trajectories of a quasi-Newton method are chaotic in the last digits: compare the objective reached
+    lg, lr = g.models[0].training_loss(), ref.models[0].training_loss()
+    assert lg == pytest.approx(lr, rel=1e-6)
+    mean, _ = g.predict(xs)
+    rmean, _ = ref.predict(xs)
+    assert np.max(np.abs(mean - rmean)) <= 1e-4 * np.max(np.abs(rmean))
+
+
+def test_exact_gp_ard_matern52_lbfgs():
+    """BASELINE config 3 shape at test size: Matern-5/2 ARD, L-BFGS-B on the exact log marginal likelihood."""
+    x, y, xs = make_regression(512, 8, n_outputs=1, n_test=64, config=3, unit=0)
+    g = GPRAS("Matern52")
+    g.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=10)
+    ref = gpras_oracle.GPRASOracle("Matern52")
+    ref.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=10)
+    assert g.models[0].lengthscales.shape == (8,)
+    assert g.models[0].training_loss() == pytest.approx(ref.models[0].training_loss(), rel=1e-7)
+    mean, var = g.predict(xs)
+    rmean, rvar = ref.predict(xs)
+    assert np.max(np.abs(mean - rmean)) <= 1e-5 * np.max(np.abs(rmean))
+    assert np.all(var > 0)
+
+
+def test_errors_surface_as_python_exceptions():
+    x, y, _ = make_regression(100, 2, config=4, unit=2)
+    g = GPRAS("RBF")
+    with pytest.raises(KeyError):
+        g.fit(x, y, 8, optimization_method="no-such")
+    g.fit(x, y, 8, "grid", "adam", max_iter=1)
+    with pytest.raises(ValueError):
+        g.predict(np.zeros((3, 5)))
+    # duplicated inducing points with a vanishing jitter-free kernel matrix are still PD thanks to the jitter
+    g.models[0].Z = np.repeat(x[:1], 8, axis=0)
+    mean, var = g.predict(x[:4])
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var))
