@@ -54,6 +54,7 @@ PROTOTYPES = {
     "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),
     "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),
     "gprx_potrf": (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _ip]),
+    "gprx_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "gprx_mfma_f64_peak": (C.c_int, [C.c_int, _dp]),
 }
 

@@ -31,6 +31,8 @@ struct GemmArgs {
   double alpha, beta;
   int flags;
   int tiles_n;
+  int tiles_m;
+  int nwg;  // launched workgroups (only tiles that touch the lower triangle when C_LOWER)
 };
 
 constexpr int GEMM_BK = 16;
@@ -109,10 +111,34 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, r = lane & 15;
 
-  const int ti = blockIdx.x / p.tiles_n;
-  const int tj = blockIdx.x % p.tiles_n;
+  // Tile index.  XCD-contiguous remap first (workgroups are dealt round-robin over the 8 XCDs, so give
+  // each XCD a contiguous run of tiles: neighbours share operand panels in that XCD's L2), then, for
+  // C_LOWER, decode the linear index over the lower trapezoid only -- every launched workgroup has
+  // work, and the tiles are spread evenly over the XCDs.
+  int bid = blockIdx.x;
+  {
+    const int q = p.nwg >> 3, rr = p.nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  int ti, tj;
+  if (p.flags & GEMM_C_LOWER) {
+    const int tn = p.tiles_n;
+    const int tri = tn * (tn + 1) / 2;
+    if (bid < tri) {
+      ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+      while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+      while (ti * (ti + 1) / 2 > bid) --ti;
+      tj = bid - ti * (ti + 1) / 2;
+    } else {
+      const int rest = bid - tri;
+      ti = tn + rest / tn;
+      tj = rest % tn;
+    }
+  } else {
+    ti = bid / p.tiles_n;
+    tj = bid % p.tiles_n;
+  }
   const int m0 = ti * BM, n0 = tj * BN;
-  if ((p.flags & GEMM_C_LOWER) && n0 > m0 + BM - 1) return;
 
   int kbeg = 0, kend = p.K;
   if (p.flags & GEMM_A_LOWER) kend = min(kend, m0 + BM);
@@ -128,6 +154,25 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // beta != 0 on a small tile: fetch C before the main loop so that its latency hides under the MFMAs
+  constexpr bool kPrefetchC = (BM * BN <= 64 * 64);
+  double cpre[kPrefetchC ? TM : 1][kPrefetchC ? TN : 1][4];
+  if constexpr (kPrefetchC) {
+    if (p.beta != 0.0) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = n0 + wn * (BN / 2) + b * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = m0 + wm * (BM / 2) + a * 16 + g + 4 * q;
+            cpre[a][b][q] = (row < p.M && col < p.N) ? p.C[(int64_t)row * p.ldc + col] : 0.0;
+          }
+        }
+    }
+  }
 
   d2 ra[BM / 32], rb[BN / 32];
   auto gload = [&](int k0) {
@@ -200,10 +245,28 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
     }
   }
 
-  // epilogue: lane holds rows g + 4q (q = 0..3) of column r of each 16 x 16 tile
+  // epilogue: lane holds rows g + 4q (q = 0..3) of column r of each 16 x 16 tile.  The C reads of a
+  // tile row are all issued before the first store (a load -> store -> load chain is latency-bound).
   const double alpha = p.alpha, beta = p.beta;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
+    double cold[TN][4];
+    if constexpr (kPrefetchC) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cold[b][q] = cpre[a][b][q];
+    } else if (beta != 0.0) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * (BN / 2) + b * 16 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + wm * (BM / 2) + a * 16 + g + 4 * q;
+          cold[b][q] = (row < p.M && col < p.N) ? p.C[(int64_t)row * p.ldc + col] : 0.0;
+        }
+      }
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int col = n0 + wn * (BN / 2) + b * 16 + r;
@@ -211,10 +274,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
       for (int q = 0; q < 4; ++q) {
         const int row = m0 + wm * (BM / 2) + a * 16 + g + 4 * q;
         if (row < p.M && col < p.N) {
-          double* cp = p.C + (int64_t)row * p.ldc + col;
           double v = alpha * acc[a][b][q];
-          if (beta != 0.0) v += beta * (*cp);
-          *cp = v;
+          if (beta != 0.0) v = __builtin_fma(beta, cold[b][q], v);
+          p.C[(int64_t)row * p.ldc + col] = v;
         }
       }
     }
@@ -223,22 +285,30 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
 
 template <int TA, int TB, int BM, int BN>
 inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p) {
-  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  if (tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  if (p.tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
+  if (p.flags & GEMM_C_LOWER) {
+    // square tiles: tile (ti, tj) touches the lower triangle iff tj <= ti
+    if (p.tiles_n > p.tiles_m) p.tiles_n = p.tiles_m;
+    p.nwg = p.tiles_n * (p.tiles_n + 1) / 2 + (p.tiles_m - p.tiles_n) * p.tiles_n;
+  } else {
+    p.nwg = p.tiles_m * p.tiles_n;
+  }
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(p.nwg), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 
 // tile: 0 = choose, 128 or 64 (square workgroup tiles)
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0) {
-  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0};
+  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0};
   if (M <= 0 || N <= 0) return hipSuccess;
   if (tile == 0) {
-    // fill the 256 CUs: 128 x 128 tiles only when there are plenty of them
+    // 128 x 128 tiles (2 workgroups per CU) once they fill the chip more than twice over; otherwise
+    // 64 x 64 tiles (4 per CU), which keep the tail short on the small updates of a factorisation
     const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_C_LOWER) ? 2 : 1);
-    tile = (t128 >= 384) ? 128 : 64;
+    tile = (t128 >= 1024) ? 128 : 64;
   }
 #define GPRX_GEMM_CASE(TA_, TB_)                                                  \
   if (ta == TA_ && tb == TB_) {                                                   \

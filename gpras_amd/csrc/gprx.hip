@@ -42,7 +42,7 @@ struct gprx_ctx {
   // data
   Buf X, Y, Z, invls, alpha, red, Kmat, invD, Xinv, Tmp, partial, xs, Ks, pred;
   // sparse path
-  Buf Xp, Zp, P, Am, Qm, Bm, invDL, invDB, SM, WP, WHP, WHQ, vecs, GPx, dZ;
+  Buf Xp, Zp, P, Am, Qm, Bm, invDL, invDB, SM, WP, WHP, WHQ, vecs, GPx, dZ, dstage;
   std::vector<double> yy;  // y.y per unit
   int ldp = 0;
   double elbo_trAAT = 0.0;
@@ -55,6 +55,7 @@ struct gprx_ctx {
   double timings[4] = {0, 0, 0, 0};
   bool profiling = false;
   PotrfProfile prof;
+  PotrfStreams pstreams;
   double prof_out[6] = {0, 0, 0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -174,6 +175,7 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
   if ((rc = ensure(h, h->Kmat, sizeof(double) * (h->np + NB) * ld))) return rc;
   if ((rc = ensure(h, h->invD, sizeof(double) * h->np * NB))) return rc;
   if ((rc = ensure(h, h->alpha, sizeof(double) * h->np))) return rc;
+  if ((rc = ensure(h, h->dstage, sizeof(double) * h->np * PW))) return rc;
   if ((rc = upload_inv_ls(h, t))) return rc;
   hipStream_t st = h->stream;
   HIPCHK(h, hipEventRecord(h->ev[0], st));
@@ -184,7 +186,7 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
   HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
   if (h->profiling) h->prof.reset();
-  HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->profiling ? &h->prof : nullptr));
+  HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->profiling ? &h->prof : nullptr, &h->pstreams));
   HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
   hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
@@ -287,6 +289,7 @@ int sgpr_alloc(gprx_handle h) {
   if ((rc = ensure(h, h->invDL, sizeof(double) * mp * NB))) return rc;
   if ((rc = ensure(h, h->invDB, sizeof(double) * mp * NB))) return rc;
   if ((rc = ensure_zeroed(h, h->vecs, sizeof(double) * (4 * mp + np)))) return rc;
+  if ((rc = ensure(h, h->dstage, sizeof(double) * std::max(mp, np) * PW))) return rc;
   return GPRX_OK;
 }
 
@@ -308,7 +311,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   HIPCHK(h, launch_kmat(st, h->kid, kq));
   HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
-  HIPCHK(h, potrf_lower(st, h->Qm.p, mp, mp, 0, h->invDL.p, h->info));
+  HIPCHK(h, potrf_lower(st, h->Qm.p, mp, mp, 0, h->invDL.p, h->info, h->dstage.p, nullptr, &h->pstreams));
   HIPCHK(h, hipMemcpyAsync(h->Am.p, h->P.p, sizeof(double) * (size_t)mp * np, hipMemcpyDeviceToDevice, st));
   HIPCHK(h, trsm_lower_left(st, h->Qm.p, mp, h->invDL.p, h->Am.p, np, mp, np));
   // B = I + A' A'^T / s (all of it: the gradient needs the symmetric matrix)
@@ -322,7 +325,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   HIPCHK(h, hipMemsetAsync(crow, 0, sizeof(double) * (size_t)NB * mp, st));
   const double* yu = h->Y.p + (size_t)unit * h->np;
   HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 1.0 / s, h->Am.p, np, yu, 1, 0.0, crow, 1, 0, 64));
-  HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info));
+  HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info, h->dstage.p, nullptr, &h->pstreams));
   HIPCHK(h, hipEventRecord(h->ev[2], st));
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, crow, mp, h->red.p);
   HIPCHK(h, hipEventRecord(h->ev[3], st));
@@ -465,13 +468,19 @@ int gprx_create(int device, int64_t n, int d, int64_t m, int kernel_id, int ard,
   h->ntheta = 2 + h->nlen;
   h->np = round_up(n, NB);
   h->mp = round_up(m, NB);
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  hipError_t e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi);
   if (e != hipSuccess) {
     delete h;
     return fail(nullptr, GPRX_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
   h->own_stream = true;
   for (auto& ev : h->ev) hipEventCreate(&ev);
+  if (h->pstreams.init() != hipSuccess) {
+    gprx_destroy(h);
+    return fail(nullptr, GPRX_EHIP, "cannot create the look-ahead stream");
+  }
   int rc;
   if ((rc = ensure(h, h->invls, sizeof(double) * d)) || (rc = ensure(h, h->red, sizeof(double) * 16))) {
     gprx_destroy(h);
@@ -492,11 +501,12 @@ int gprx_destroy(gprx_handle h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
                  &h->pred, &h->Xp, &h->Zp, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs,
-                 &h->GPx, &h->dZ})
+                 &h->GPx, &h->dZ, &h->dstage})
     if (b->p) hipFree(b->p);
   if (h->info) hipFree(h->info);
   for (auto& ev : h->ev)
     if (ev) hipEventDestroy(ev);
+  h->pstreams.destroy();
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return GPRX_OK;
@@ -777,13 +787,41 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   int* dinfo = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dinfo, sizeof(int)));
   HIPCHK(nullptr, hipMemset(dinfo, 0, sizeof(int)));
-  hipError_t e = potrf_lower(nullptr, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo);
+  PotrfStreams ps;
+  hipStream_t st = nullptr;
+  HIPCHK(nullptr, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  HIPCHK(nullptr, ps.init());
+  double* dstage = nullptr;
+  HIPCHK(nullptr, hipMalloc((void**)&dstage, sizeof(double) * np * PW));
+  hipError_t e = potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
   hipError_t e2 = hipDeviceSynchronize();
+  hipFree(dstage);
+  ps.destroy();
+  hipStreamDestroy(st);
   hipMemcpy(info_host, dinfo, sizeof(int), hipMemcpyDeviceToHost);
   hipFree(dinfo);
   HIPCHK(nullptr, e);
   HIPCHK(nullptr, e2);
   return *info_host ? fail(nullptr, GPRX_ENOTPD, "matrix not positive definite") : GPRX_OK;
+}
+
+#ifdef GPRX_PANEL_STAMPS
+int gprx_panel_stamps(unsigned long long* out64) {
+  hipMemcpyFromSymbol(out64, HIP_SYMBOL(gprx::g_panel_stamps), sizeof(unsigned long long) * 64);
+  return 0;
+}
+#endif
+
+int gprx_set_tuning(const char* key, int value) {
+  if (!key) return fail(nullptr, GPRX_EINVAL, "null key");
+  PotrfTuning& t = potrf_tuning();
+  const std::string k(key);
+  if (k == "panel_width" && (value == 0 || value == 64 || value == 128)) t.panel_width = value;
+  else if (k == "outer_block" && value >= 0 && value % 128 == 0) t.outer_block = value;
+  else if (k == "update_tile" && (value == 0 || value == 64 || value == 128)) t.update_tile = value;
+  else if (k == "no_lookahead") t.no_lookahead = value != 0;
+  else return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
+  return GPRX_OK;
 }
 
 int gprx_mfma_f64_peak(int device, double* tflops) {

@@ -3,14 +3,15 @@
 // Per 64-column panel two launches:
 //   1. potrf_panel_kernel  -- factor the 64 x 64 diagonal block AND solve every row below it
 //      (L21 = A21 L11^-T, including the right-hand-side rows appended under the matrix) in one
-//      launch.  A workgroup keeps 256 panel rows in LDS (stride 65: row-per-lane access is
-//      conflict-free): the 64 rows of the diagonal block -- every workgroup re-factors it
-//      redundantly, so no inter-workgroup hand-off exists -- plus 192 rows of A21.  Work proceeds
-//      in 8-column sub-panels: each thread factors the 8 x 8 diagonal sub-block (register math)
-//      and solves its own row, then the columns right of the sub-panel are updated on MFMA
-//      (rows x 8 times (64 x 8)^T); two barriers per sub-panel.  One extra workgroup carries the
-//      64 identity rows, which come out as L11^-1 (inverse of the diagonal block, used by the
-//      triangular solves).
+//      launch.  A workgroup owns 128 panel rows: the 64 rows of the diagonal block -- every workgroup
+//      re-factors it redundantly, so no inter-workgroup hand-off exists -- plus 64 rows of A21.
+//      The 128 x 64 panel lives in the MFMA accumulators (wave w: rows 32 w .. 32 w + 31).  Work
+//      proceeds in 8-column sub-panels: the sub-panel's columns go accumulators -> LDS, each thread
+//      factors the 8 x 8 diagonal sub-block (register math) and solves its own row, then the
+//      columns right of the sub-panel are updated on MFMA (rows x 8 times (64 x 8)^T) with the
+//      operands read once from LDS and no read-modify-write of C; two barriers per sub-panel.  One
+//      extra workgroup carries the 64 identity rows, which come out as L11^-1 (inverse of the
+//      diagonal block, used by the triangular solves).
 //   2. gemm_f64 (NT, C_LOWER, alpha = -1, beta = 1) -- trailing update A22 -= L21 L21^T on MFMA.
 #pragma once
 #include <utility>
@@ -21,145 +22,409 @@
 
 namespace gprx {
 
-constexpr int PANEL_ROWS = 192;  // rows of A21 per workgroup (LDS rows 64..255)
-constexpr int PLD = 65;          // LDS row stride (doubles): lane t -> bank 2t, conflict-free row-per-lane b64 access
+#ifdef GPRX_PANEL_STAMPS
+__device__ unsigned long long g_panel_stamps[64];
+#define PSTAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_panel_stamps[i] = __builtin_amdgcn_s_memtime();
+#else
+#define PSTAMP(i)
+#endif
 
-// A points at the diagonal block (c, c).  rows_below = rows under the block to solve.
-// LDS image: sRow[256][65]: rows 0..63 = diagonal block (every workgroup factors it redundantly),
-// rows 64..255 = this workgroup's 192 rows of A21 (or, in the last workgroup, the 64 identity rows).
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
-                                                          double* __restrict__ inv_diag, int* __restrict__ info, int col0) {
-  __shared__ __attribute__((aligned(16))) double sRow[256 * PLD];
-  __shared__ __attribute__((aligned(16))) double sD[8][8];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, r = lane & 15;
-  const bool last = (int)blockIdx.x == nchunks;
+constexpr int PANEL_ROWS = 64;   // rows of A21 per workgroup (workgroup rows 64..127; rows 0..63 = the diagonal block)
+constexpr int PWG_ROWS = 128;    // rows held by one workgroup
+constexpr int PSUB = 9;          // LDS row stride of the 8-column sub-panel buffers (row-per-lane b64 access conflict-free)
+constexpr int POUT = NB + 1;     // LDS row stride of the output image
 
-  // ---- coalesced load: 256 rows x 32 chunks of 16 B ----
-#pragma unroll 4
-  for (int i = 0; i < 32; ++i) {
-    const int q = tid + 256 * i;
-    const int row = q >> 5, cc = q & 31;
-    d2 v = d2{0.0, 0.0};
-    if (row < NB) {
-      v = *reinterpret_cast<const d2*>(A + (int64_t)row * lda + 2 * cc);
-      if (2 * cc > row) v.x = 0.0;
-      if (2 * cc + 1 > row) v.y = 0.0;
-    } else if (!last) {
-      const int idx = blockIdx.x * PANEL_ROWS + (row - NB);
-      if (idx < rows_below) v = *reinterpret_cast<const d2*>(A + (int64_t)(NB + idx) * lda + 2 * cc);
-    } else {
-      const int e = row - NB;  // identity rows (only the first 64 are meaningful)
-      if (2 * cc == e) v.x = 1.0;
-      if (2 * cc + 1 == e) v.y = 1.0;
-    }
-    sRow[row * PLD + 2 * cc] = v.x;
-    sRow[row * PLD + 2 * cc + 1] = v.y;
+// State shared by the unrolled sub-panel steps.
+struct PanelCtx {
+  double* sIn;    // [128][9]  current sub-panel, as updated so far (written from the accumulators)
+  double* sX;     // [128][9]  current sub-panel, solved (MFMA operands of the trailing update)
+  double* sOut;   // [128][65] all solved columns (coalesced store at the end)
+  int tid, wave, g, r;
+  int zero_above;  // diagonal-block rows: entries right of the diagonal are zero
+  int bad;
+};
+
+// One 8-column sub-panel.  acc[rt][kt]: this wave's 32 rows x 64 columns in MFMA C/D layout
+// (lane (g, r) holds rows 32 w + 16 rt + g + 4 q, column 16 kt + r).
+template <int P>
+__device__ __forceinline__ void panel_step(d4 (&acc)[2][4], PanelCtx& c) {
+  constexpr int C0 = 8 * P;
+  constexpr int KT = C0 / 16;      // tile column holding this sub-panel
+  constexpr int HALF = P & 1;      // which 8 columns of that tile
+  if constexpr (P == 1) { PSTAMP(10) }
+  // A: accumulators -> LDS (only the lanes that hold these 8 columns)
+  if ((c.r >> 3) == HALF) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c.sIn[(32 * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)] = acc[rt][KT][q];
   }
   __syncthreads();
-
-  double* myrow = sRow + tid * PLD;
-  const int zero_above = tid < NB ? tid : (1 << 30);  // diagonal-block rows: entries right of the diagonal are zero
-  int bad = 0;
-
-  for (int p = 0; p < 8; ++p) {
-    const int C0 = 8 * p;
-    if (tid >= C0 && tid < C0 + 8) {
+  if constexpr (P == 1) { PSTAMP(11) }
+  // B: every thread factors the 8 x 8 diagonal sub-block (rows C0 .. C0+7 of the diagonal block)
+  double l[8][8], rinv[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sD[tid - C0][k] = myrow[C0 + k];
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int k = 0; k <= j; ++k) l[j][k] = c.sIn[(C0 + j) * PSUB + k];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double s = l[j][j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) s = __builtin_fma(-l[j][m], l[j][m], s);
+    if (!(s > 0.0)) {
+      if (c.bad == 0) c.bad = C0 + j + 1;
+      s = 1.0;
     }
-    __syncthreads();
-    // every thread factors the 8 x 8 diagonal sub-block
-    double l[8][8], rinv[8];
+    const double ri = rsqrt_f64(s);
+    rinv[j] = ri;
+    l[j][j] = s * ri;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int i = j + 1; i < 8; ++i) {
+      double t = l[i][j];
 #pragma unroll
-      for (int k = 0; k <= j; ++k) l[j][k] = sD[j][k];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      double s = l[j][j];
-#pragma unroll
-      for (int m = 0; m < j; ++m) s = __builtin_fma(-l[j][m], l[j][m], s);
-      if (!(s > 0.0)) {
-        if (bad == 0) bad = C0 + j + 1;
-        s = 1.0;
-      }
-      const double ri = rsqrt_f64(s);
-      rinv[j] = ri;
-      l[j][j] = s * ri;
-#pragma unroll
-      for (int i = j + 1; i < 8; ++i) {
-        double t = l[i][j];
-#pragma unroll
-        for (int m = 0; m < j; ++m) t = __builtin_fma(-l[i][m], l[j][m], t);
-        l[i][j] = t * ri;
-      }
+      for (int m = 0; m < j; ++m) t = __builtin_fma(-l[i][m], l[j][m], t);
+      l[i][j] = t * ri;
     }
+  }
+  if constexpr (P == 1) { PSTAMP(12) }
+  if (c.tid < PWG_ROWS) {
     // own row: x = a[C0 .. C0+7] L_dd^-T
     double x[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      double t = myrow[C0 + k];
+      double t = c.sIn[c.tid * PSUB + k];
 #pragma unroll
       for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], l[k][m], t);
-      x[k] = (C0 + k > zero_above) ? 0.0 : t * rinv[k];
+      x[k] = (C0 + k > c.zero_above) ? 0.0 : t * rinv[k];
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) myrow[C0 + k] = x[k];
-    __syncthreads();
-    // trailing columns [C0 + 8, 64): rows(256 x 8) * Lpanel(64 x 8)^T on MFMA.  Wave w owns rows 64w .. 64w+63.
-    if (C0 + 8 < NB) {
-      double fa[4][2];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -sRow[(wave * 64 + rt * 16 + r) * PLD + C0 + 4 * ks + g];
-      for (int kt = (C0 + 8) >> 4; kt < 4; ++kt) {
-        const int kk = kt * 16 + r;
-        double fb[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb[ks] = (kk >= C0 + 8) ? sRow[kk * PLD + C0 + 4 * ks + g] : 0.0;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          double* cp = sRow + (wave * 64 + rt * 16 + g) * PLD + kt * 16 + r;
-          d4 c = d4{cp[0], cp[4 * PLD], cp[8 * PLD], cp[12 * PLD]};
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[1], c, 0, 0, 0);
-          cp[0] = c[0];
-          cp[4 * PLD] = c[1];
-          cp[8 * PLD] = c[2];
-          cp[12 * PLD] = c[3];
-        }
-      }
+    for (int k = 0; k < 8; ++k) {
+      c.sX[c.tid * PSUB + k] = x[k];
+      c.sOut[c.tid * POUT + C0 + k] = x[k];
     }
   }
+  if constexpr (P == 1) { PSTAMP(13) }
   __syncthreads();
+  if constexpr (P == 1) { PSTAMP(14) }
+  // C: trailing columns [C0 + 8, 64) of this wave's rows: acc -= X_rows (32 x 8) * X_diag(16 kt .. +15, 8)^T
+  if constexpr (C0 + 8 < NB) {
+    constexpr int KT0 = (C0 + 8) / 16;
+    double fa[2][2], fb[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -c.sX[(32 * c.wave + 16 * rt + c.r) * PSUB + 4 * ks + c.g];
+#pragma unroll
+    for (int kt = KT0; kt < 4; ++kt) {
+      const int kk = kt * 16 + c.r;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb[kt][ks] = (kk >= C0 + 8) ? c.sX[kk * PSUB + 4 * ks + c.g] : 0.0;
+    }
+    // the tile column that the next sub-panel reads goes first; the rest may still be in the MFMA pipe
+    // while the next sub-panel's factorisation runs on the VALU
+#pragma unroll
+    for (int kt = KT0; kt < 4; ++kt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
+      }
+  }
+  if constexpr (P == 1) { PSTAMP(15) }
+}
 
-  // ---- coalesced store ----
+// A points at the diagonal block (c, c).  rows_below = rows under the block to solve.
+// Workgroup rows 0..63 = the diagonal block (every workgroup factors it redundantly), rows 64..127 =
+// this workgroup's 64 rows of A21 (or, in the last workgroup, the 64 identity rows -> L11^-1).
+//
+// In-place hazard: every workgroup reads the diagonal block, so none of them may overwrite it during
+// this launch (a late-dispatched workgroup would read L11 instead of A11).  The last workgroup writes
+// L11 to `stage_out` instead, and copies the PREVIOUS panel's staged block (`prev_stage`, prev_pw x
+// prev_pw) to its place `prev_dst` in the matrix -- all readers of that block finished with the
+// previous launch.  potrf_lower flushes the final block with copy_block_kernel.
+__device__ __forceinline__ void flush_staged_block(const double* __restrict__ prev_stage, double* __restrict__ prev_dst, int64_t lda,
+                                                   int prev_pw, int tid) {
+  if (!prev_stage) return;
+  const int chunks = prev_pw / 2;  // 16-byte chunks per row
+  for (int e = tid; e < prev_pw * chunks; e += 256) {
+    const int row = e / chunks, cc = e % chunks;
+    *reinterpret_cast<d2*>(prev_dst + (int64_t)row * lda + 2 * cc) = *reinterpret_cast<const d2*>(prev_stage + row * prev_pw + 2 * cc);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_block_kernel(const double* __restrict__ stage, double* __restrict__ dst, int64_t lda, int pw) {
+  flush_staged_block(stage, dst, lda, pw, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
+                                                          double* __restrict__ inv_diag, int* __restrict__ info, int col0,
+                                                          double* __restrict__ stage_out, const double* __restrict__ prev_stage,
+                                                          double* __restrict__ prev_dst, int prev_pw) {
+  __shared__ __attribute__((aligned(16))) double sIn[PWG_ROWS * PSUB];
+  __shared__ __attribute__((aligned(16))) double sX[PWG_ROWS * PSUB];
+  __shared__ __attribute__((aligned(16))) double sOut[PWG_ROWS * POUT];
+  PanelCtx c;
+  c.sIn = sIn;
+  c.sX = sX;
+  c.sOut = sOut;
+  c.tid = threadIdx.x;
+  const int lane = c.tid & 63;
+  c.wave = c.tid >> 6;
+  c.g = lane >> 4;
+  c.r = lane & 15;
+  c.zero_above = c.tid < NB ? c.tid : (1 << 30);
+  c.bad = 0;
+  const bool last = (int)blockIdx.x == nchunks;
+  if (last) flush_staged_block(prev_stage, prev_dst, lda, prev_pw, c.tid);
+  PSTAMP(0)
+
+  // ---- load straight into the accumulator layout (32 loads per lane, all in flight) ----
+  d4 acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int wrow = 32 * c.wave + 16 * rt + c.g + 4 * q;  // workgroup row 0..127
+      const double* src = nullptr;
+      if (wrow < NB) {
+        src = A + (int64_t)wrow * lda;
+      } else if (!last) {
+        const int idx = blockIdx.x * PANEL_ROWS + (wrow - NB);
+        if (idx < rows_below) src = A + (int64_t)(NB + idx) * lda;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int col = kt * 16 + c.r;
+        double v = 0.0;
+        if (src) v = src[col];
+        if (wrow < NB) {
+          if (col > wrow) v = 0.0;
+        } else if (last) {
+          v = (col == wrow - NB) ? 1.0 : 0.0;
+        }
+        acc[rt][kt][q] = v;
+      }
+    }
+  PSTAMP(1)
+
+  panel_step<0>(acc, c);
+  PSTAMP(2)
+  panel_step<1>(acc, c);
+  panel_step<2>(acc, c);
+  panel_step<3>(acc, c);
+  PSTAMP(3)
+  panel_step<4>(acc, c);
+  panel_step<5>(acc, c);
+  panel_step<6>(acc, c);
+  panel_step<7>(acc, c);
+  __syncthreads();
+  PSTAMP(4)
+
+  // ---- coalesced store from the output image: 128 rows x 32 chunks of 16 B ----
   if (!last) {
-#pragma unroll 4
-    for (int i = 8; i < 32; ++i) {  // rows 64..255
-      const int q = tid + 256 * i;
+#pragma unroll
+    for (int i = 8; i < 16; ++i) {  // workgroup rows 64..127
+      const int q = c.tid + 256 * i;
       const int row = q >> 5, cc = q & 31;
       const int idx = blockIdx.x * PANEL_ROWS + (row - NB);
       if (idx < rows_below)
-        *reinterpret_cast<d2*>(A + (int64_t)(NB + idx) * lda + 2 * cc) = d2{sRow[row * PLD + 2 * cc], sRow[row * PLD + 2 * cc + 1]};
+        *reinterpret_cast<d2*>(A + (int64_t)(NB + idx) * lda + 2 * cc) = d2{sOut[row * POUT + 2 * cc], sOut[row * POUT + 2 * cc + 1]};
     }
   } else {
-#pragma unroll 4
-    for (int i = 0; i < 8; ++i) {  // the factored diagonal block, zeros right of the diagonal
-      const int q = tid + 256 * i;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // the factored diagonal block (zeros right of the diagonal) -> staging
+      const int q = c.tid + 256 * i;
       const int row = q >> 5, cc = q & 31;
-      *reinterpret_cast<d2*>(A + (int64_t)row * lda + 2 * cc) = d2{sRow[row * PLD + 2 * cc], sRow[row * PLD + 2 * cc + 1]};
+      *reinterpret_cast<d2*>(stage_out + row * NB + 2 * cc) = d2{sOut[row * POUT + 2 * cc], sOut[row * POUT + 2 * cc + 1]};
     }
     // identity row i came out as column i of L11^-1
-    for (int e = tid; e < NB * NB; e += 256) {
+    for (int e = c.tid; e < NB * NB; e += 256) {
       const int kk = e >> 6, i = e & 63;
-      inv_diag[e] = sRow[(NB + i) * PLD + kk];
+      inv_diag[e] = sOut[(NB + i) * POUT + kk];
     }
-    if (tid == 0 && bad != 0) atomicCAS(info, 0, col0 + bad);
+    if (c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
   }
+  PSTAMP(5)
+}
+
+// ---- 128-column panel: the same algorithm with a 128 x 128 diagonal block ------------------------
+// Workgroup rows 0..127 = the diagonal block, rows 128..255 = 128 rows of A21 (last workgroup: 128
+// identity rows).  Wave w owns workgroup rows 64 w .. 64 w + 63: acc[4][8] = 64 rows x 128 columns.
+// LDS holds only the two 8-column sub-panel buffers (18 KiB); solved values go straight to memory
+// (one thread = one row, 64 contiguous bytes per sub-panel).
+constexpr int PW = 128;
+
+struct Panel128Ctx {
+  double* sIn;   // [256][9]
+  double* sX;    // [256][9]
+  double* out;   // this thread's output row in global memory (nullptr: nothing to write)
+  double* inv_diag;
+  int tid, wave, g, r;
+  int zero_above;
+  int ident;     // >= 0: this thread carries identity row `ident` (last workgroup)
+  int bad;
+};
+
+template <int P>
+__device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c) {
+  constexpr int C0 = 8 * P;
+  constexpr int KT = C0 / 16;
+  constexpr int HALF = P & 1;
+  if ((c.r >> 3) == HALF) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c.sIn[(64 * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)] = acc[rt][KT][q];
+  }
+  __syncthreads();
+  double l[8][8], rinv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int k = 0; k <= j; ++k) l[j][k] = c.sIn[(C0 + j) * PSUB + k];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double s = l[j][j];
+#pragma unroll
+    for (int m = 0; m < j; ++m) s = __builtin_fma(-l[j][m], l[j][m], s);
+    if (!(s > 0.0)) {
+      if (c.bad == 0) c.bad = C0 + j + 1;
+      s = 1.0;
+    }
+    const double ri = rsqrt_f64(s);
+    rinv[j] = ri;
+    l[j][j] = s * ri;
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      double t = l[i][j];
+#pragma unroll
+      for (int m = 0; m < j; ++m) t = __builtin_fma(-l[i][m], l[j][m], t);
+      l[i][j] = t * ri;
+    }
+  }
+  double x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double t = c.sIn[c.tid * PSUB + k];
+#pragma unroll
+    for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], l[k][m], t);
+    x[k] = (C0 + k > c.zero_above) ? 0.0 : t * rinv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c.sX[c.tid * PSUB + k] = x[k];
+  if (c.out) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) *reinterpret_cast<d2*>(c.out + C0 + k) = d2{x[k], x[k + 1]};
+  }
+  if (c.ident >= 0) {
+    // identity row i: x[k] = (L11^-1)[C0 + k][i]; keep the two 64 x 64 diagonal blocks of the inverse
+    constexpr int BLK = C0 / NB;
+    if ((c.ident / NB) == BLK) {
+      const int i = c.ident - BLK * NB;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c.inv_diag[BLK * NB * NB + (C0 - BLK * NB + k) * NB + i] = x[k];
+    }
+  }
+  __syncthreads();
+  if constexpr (C0 + 8 < PW) {
+    constexpr int KT0 = (C0 + 8) / 16;
+    double fa[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -c.sX[(64 * c.wave + 16 * rt + c.r) * PSUB + 4 * ks + c.g];
+#pragma unroll
+    for (int kt = KT0; kt < 8; ++kt) {
+      const int kk = kt * 16 + c.r;
+      const double fb0 = (kk >= C0 + 8) ? c.sX[kk * PSUB + c.g] : 0.0;
+      const double fb1 = (kk >= C0 + 8) ? c.sX[kk * PSUB + 4 + c.g] : 0.0;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb0, acc[rt][kt], 0, 0, 0);
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb1, acc[rt][kt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+constexpr int PANEL128_ROWS = 128;  // rows of A21 per workgroup
+
+__global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
+                                                             double* __restrict__ inv_diag, int* __restrict__ info, int col0,
+                                                             double* __restrict__ stage_out, const double* __restrict__ prev_stage,
+                                                             double* __restrict__ prev_dst, int prev_pw) {
+  __shared__ __attribute__((aligned(16))) double sIn[256 * PSUB];
+  __shared__ __attribute__((aligned(16))) double sX[256 * PSUB];
+  Panel128Ctx c;
+  c.sIn = sIn;
+  c.sX = sX;
+  c.tid = threadIdx.x;
+  const int lane = c.tid & 63;
+  c.wave = c.tid >> 6;
+  c.g = lane >> 4;
+  c.r = lane & 15;
+  c.zero_above = c.tid < PW ? c.tid : (1 << 30);
+  c.bad = 0;
+  c.inv_diag = inv_diag;
+  const bool last = (int)blockIdx.x == nchunks;
+  // output row of this thread
+  c.out = nullptr;
+  c.ident = -1;
+  if (last) flush_staged_block(prev_stage, prev_dst, lda, prev_pw, c.tid);
+  if (c.tid < PW) {
+    if (last) c.out = stage_out + c.tid * PW;  // staged: see the in-place hazard note above
+  } else if (!last) {
+    const int idx = blockIdx.x * PANEL128_ROWS + (c.tid - PW);
+    if (idx < rows_below) c.out = A + (int64_t)(PW + idx) * lda;
+  } else {
+    c.ident = c.tid - PW;
+  }
+
+  d4 acc[4][8];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int wrow = 64 * c.wave + 16 * rt + c.g + 4 * q;  // workgroup row 0..255
+      const double* src = nullptr;
+      if (wrow < PW) {
+        src = A + (int64_t)wrow * lda;
+      } else if (!last) {
+        const int idx = blockIdx.x * PANEL128_ROWS + (wrow - PW);
+        if (idx < rows_below) src = A + (int64_t)(PW + idx) * lda;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const int col = kt * 16 + c.r;
+        double v = 0.0;
+        if (src) v = src[col];
+        if (wrow < PW) {
+          if (col > wrow) v = 0.0;
+        } else if (last) {
+          v = (col == wrow - PW) ? 1.0 : 0.0;
+        }
+        acc[rt][kt][q] = v;
+      }
+    }
+
+  panel128_step<0>(acc, c);
+  panel128_step<1>(acc, c);
+  panel128_step<2>(acc, c);
+  panel128_step<3>(acc, c);
+  panel128_step<4>(acc, c);
+  panel128_step<5>(acc, c);
+  panel128_step<6>(acc, c);
+  panel128_step<7>(acc, c);
+  panel128_step<8>(acc, c);
+  panel128_step<9>(acc, c);
+  panel128_step<10>(acc, c);
+  panel128_step<11>(acc, c);
+  panel128_step<12>(acc, c);
+  panel128_step<13>(acc, c);
+  panel128_step<14>(acc, c);
+  panel128_step<15>(acc, c);
+  if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
 }
 
 // Optional per-launch timing of the two kernels of the factorisation (HIP events on the launch stream).
@@ -186,36 +451,148 @@ struct PotrfProfile {
   }
 };
 
+// Streams and events of the look-ahead schedule (owned by the caller, reused across factorisations).
+struct PotrfStreams {
+  hipStream_t aux = nullptr;
+  hipEvent_t block_done = nullptr, tail_done = nullptr;
+  hipError_t init() {
+    // lowest priority: the bulk TAIL updates must not take CUs from the panel chain on the main stream
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipError_t e = hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, lo);
+    if (e != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&block_done, hipEventDisableTiming)) != hipSuccess) return e;
+    return hipEventCreateWithFlags(&tail_done, hipEventDisableTiming);
+  }
+  void destroy() {
+    if (aux) hipStreamDestroy(aux);
+    if (block_done) hipEventDestroy(block_done);
+    if (tail_done) hipEventDestroy(tail_done);
+    aux = nullptr;
+    block_done = tail_done = nullptr;
+  }
+};
+
 // Factor the (np x np) matrix in place; `extra` rows below it are carried as right-hand sides.
 // inv_diag: np/64 blocks of 64 x 64.  info (device int) must be zeroed by the caller.
+//
+// Two-level right-looking schedule with look-ahead.  Panels are 64 columns wide by default (one launch
+// factors the diagonal block and solves all rows below it; the 128-column kernel is selectable with
+// gprx_set_tuning and measured slower: its MFMA updates serialise behind the scalar factor chain).
+// Outer blocks are `ob` columns (256 below n = 8192, else 512, measured): the bulk trailing updates
+// run with K = ob, i.e. n / ob passes over the trailing matrix instead of n / 64.  For each outer block J =
+// columns [C, C + w):
+//   main stream: its panels, each followed by the strip update of the block's remaining columns;
+//                then HEAD(J): the update of the NEXT block's columns by block J (K = w);
+//   aux stream : TAIL(J): the update of every column right of the next block (K = w, the bulk of the
+//                flops), overlapping the next block's panel chain on the main stream.
+// Order: TAIL(J) waits for HEAD(J) to be enqueued behind block J (event) and follows TAIL(J-1)
+// (stream order); HEAD(J) waits for TAIL(J-1), the last writer of the next block's columns.
+// run-time tuning knobs (gprx_set_tuning): 0 = default heuristics
+struct PotrfTuning {
+  int panel_width = 0;   // 64 or 128
+  int outer_block = 0;   // multiple of 128
+  int update_tile = 0;   // tile of the TAIL GEMM: 64 or 128
+  int no_lookahead = 0;  // 1: everything on the main stream (debugging)
+};
+inline PotrfTuning& potrf_tuning() {
+  static PotrfTuning t;
+  return t;
+}
+
+// diag_stage: scratch of np * 128 doubles (staged diagonal blocks, see potrf_panel_kernel)
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
-                              PotrfProfile* prof = nullptr) {
-  for (int c = 0; c < np; c += NB) {
-    const int rows_below = np - c - NB + extra;
-    const int nchunks = (rows_below + PANEL_ROWS - 1) / PANEL_ROWS;
-    double* Acc = A + (int64_t)c * lda + c;
-    if (prof) {
-      prof->panel_marks.push_back(prof->used);
-      hipEventRecord(prof->next(), st);
-    }
-    hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                       inv_diag + (int64_t)(c / NB) * NB * NB, info, c);
-    if (prof) hipEventRecord(prof->next(), st);
-    const int ncols = np - c - NB;
-    if (ncols > 0) {
-      double* L21 = A + (int64_t)(c + NB) * lda + c;
-      double* A22 = A + (int64_t)(c + NB) * lda + (c + NB);
+                              double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr) {
+  const double* prev_stage = nullptr;
+  double* prev_dst = nullptr;
+  int prev_pw = 0;
+  auto mark_gemm = [&](hipStream_t s, int ncols_lower, int rows_rect, int ncols, int k) {
+    if (!prof) return;
+    // algorithmic flops: 2 K per updated element (lower triangle incl. diagonal of the square part + rectangle)
+    const double elems = 0.5 * (double)ncols_lower * (ncols_lower + 1) + (double)rows_rect * ncols;
+    prof->gemm_marks.push_back({prof->used, 2.0 * k * elems});
+    hipEventRecord(prof->next(), s);
+  };
+  auto mark_end = [&](hipStream_t s) {
+    if (prof) hipEventRecord(prof->next(), s);
+  };
+  const int total_rows = np + extra;
+  const PotrfTuning& tune = potrf_tuning();
+  if (tune.no_lookahead) ps = nullptr;
+  const int ob = tune.outer_block ? tune.outer_block : (np >= 8192 ? 512 : 256);
+  const int pwidth = tune.panel_width ? tune.panel_width : NB;
+  bool tail_pending = false;
+  for (int C = 0; C < np; C += ob) {
+    const int w = (np - C < ob) ? np - C : ob;
+    int c = C;
+    while (c < C + w) {
+      const int pw = (pwidth == PW && C + w - c >= PW) ? PW : NB;  // 128-column panel, or 64 columns
+      const int rows_below = total_rows - c - pw;
+      double* Acc = A + (int64_t)c * lda + c;
       if (prof) {
-        // algorithmic flops: 2 K per updated element of the lower trapezoid (diagonal included)
-        const double elems = 0.5 * (double)ncols * (ncols + 1) + (double)extra * ncols;
-        prof->gemm_marks.push_back({prof->used, 2.0 * NB * elems});
+        prof->panel_marks.push_back(prof->used);
         hipEventRecord(prof->next(), st);
       }
-      hipError_t e = launch_gemm(st, 0, 1, rows_below, ncols, NB, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER);
+      double* stage_out = diag_stage + (int64_t)c * PW;
+      if (pw == PW) {
+        const int nchunks = (rows_below + PANEL128_ROWS - 1) / PANEL128_ROWS;
+        hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                           inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+      } else {
+        const int nchunks = (rows_below + PANEL_ROWS - 1) / PANEL_ROWS;
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                           inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+      }
+      prev_stage = stage_out;
+      prev_dst = Acc;
+      prev_pw = pw;
       if (prof) hipEventRecord(prof->next(), st);
+      const int strip = C + w - c - pw;  // remaining columns of this outer block
+      if (strip > 0) {
+        double* L21 = A + (int64_t)(c + pw) * lda + c;
+        double* A22 = A + (int64_t)(c + pw) * lda + (c + pw);
+        mark_gemm(st, strip, rows_below - strip, strip, pw);
+        hipError_t e = launch_gemm(st, 0, 1, rows_below, strip, pw, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64);
+        mark_end(st);
+        if (e != hipSuccess) return e;
+      }
+      c += pw;
+    }
+    const int R = C + w;  // first column right of this block
+    if (R >= np) break;
+    const int wn = (np - R < ob) ? np - R : ob;     // width of the next block
+    const double* Lpan = A + (int64_t)R * lda + C;  // L[R:, C:C+w]
+    // HEAD(J): columns [R, R + wn), rows [R, total_rows)
+    if (ps && tail_pending) hipStreamWaitEvent(st, ps->tail_done, 0);
+    {
+      const int rows = total_rows - R;
+      mark_gemm(st, wn, rows - wn, wn, w);
+      hipError_t e = launch_gemm(st, 0, 1, rows, wn, w, -1.0, Lpan, lda, Lpan, lda, 1.0, A + (int64_t)R * lda + R, lda, GEMM_C_LOWER, 64);
+      mark_end(st);
       if (e != hipSuccess) return e;
     }
+    if (ps) hipEventRecord(ps->block_done, st);
+    // TAIL(J): columns [R + wn, np), rows [R + wn, total_rows)
+    const int R2 = R + wn;
+    if (R2 < np) {
+      hipStream_t ts = ps ? ps->aux : st;
+      if (ps) hipStreamWaitEvent(ts, ps->block_done, 0);
+      const int rows = total_rows - R2, cols = np - R2;
+      const double* Lrow = A + (int64_t)R2 * lda + C;  // L[R2:, C:C+w]
+      mark_gemm(ts, cols, rows - cols, cols, w);
+      hipError_t e = launch_gemm(ts, 0, 1, rows, cols, w, -1.0, Lrow, lda, Lrow, lda, 1.0, A + (int64_t)R2 * lda + R2, lda, GEMM_C_LOWER, tune.update_tile);
+      mark_end(ts);
+      if (e != hipSuccess) return e;
+      if (ps) {
+        hipEventRecord(ps->tail_done, ts);
+        tail_pending = true;
+      }
+    }
   }
+  // the last panel's diagonal block is still staged
+  if (prev_stage) hipLaunchKernelGGL(copy_block_kernel, dim3(1), dim3(256), 0, st, prev_stage, prev_dst, lda, prev_pw);
+  // everything later on `st` must see the aux stream's last update
+  if (ps && tail_pending) hipStreamWaitEvent(st, ps->tail_done, 0);
   return hipGetLastError();
 }
 

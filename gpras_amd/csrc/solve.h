@@ -53,34 +53,52 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ 
 }
 
 // Step i of the backward solve L^T x = b (i runs from nblocks-1 down):
-//   every workgroup j < i:  b_j -= L[i, j]^T x_i   (thread per column, 64 rows of the block row i)
+//   every workgroup j < i:  b_j -= L[i, j]^T x_i   (64 x 64 block; 4 row groups of 16, all 16 loads of a
+//                                                   thread in flight at once, then an LDS reduction)
 //   workgroup j == i - 1 then forms x_{i-1} = invD_{i-1}^T b_{i-1}.
 // Step i == nblocks only forms x_{nblocks-1}.
-__global__ __launch_bounds__(64) void trsv_bwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
-                                                    double* __restrict__ b, int i, int nblocks) {
+__global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
+                                                     double* __restrict__ b, int i, int nblocks) {
   __shared__ double sx[NB];
   __shared__ double sb[NB];
-  const int t = threadIdx.x;
+  __shared__ double part[4][NB];
+  const int tid = threadIdx.x;
+  const int t = tid & 63, grp = tid >> 6;
   const int j = i - 1 - (int)blockIdx.x;
   if (j < 0) return;
-  double v = b[j * NB + t];
   if (i < nblocks) {
-    sx[t] = b[i * NB + t];
+    if (tid < NB) sx[tid] = b[i * NB + tid];
+    const double* lp = L + (int64_t)(i * NB + grp * 16) * lda + j * NB + t;
+    double lv[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) lv[m] = lp[(int64_t)m * lda];
     __syncthreads();
-    const double* lp = L + (int64_t)(i * NB) * lda + j * NB + t;
     double s = 0.0;
-#pragma unroll 8
-    for (int m = 0; m < NB; ++m) s = __builtin_fma(lp[(int64_t)m * lda], sx[m], s);
-    v -= s;
-    b[j * NB + t] = v;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s = __builtin_fma(lv[m], sx[grp * 16 + m], s);
+    part[grp][t] = s;
+    __syncthreads();
+    if (tid < NB) {
+      const double v = b[j * NB + tid] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+      b[j * NB + tid] = v;
+      sb[tid] = v;
+    }
+  } else {
+    if (tid < NB) sb[tid] = b[j * NB + tid];
   }
   if (j != i - 1) return;
-  sb[t] = v;
   __syncthreads();
+  // x_j[t] = sum_{m >= t} invD_j[m][t] b_j[m]; 4 groups split the rows m
   const double* ip = inv_diag + (int64_t)j * NB * NB;
   double s = 0.0;
-  for (int m = t; m < NB; ++m) s = __builtin_fma(ip[m * NB + t], sb[m], s);
-  b[j * NB + t] = s;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int mm = grp * 16 + m;
+    s = __builtin_fma(ip[mm * NB + t], sb[mm], s);  // invD is lower triangular with explicit zeros above
+  }
+  part[grp][t] = s;
+  __syncthreads();
+  if (tid < NB) b[j * NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
 inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* b, int np, bool transpose) {
@@ -90,7 +108,7 @@ inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const
       hipLaunchKernelGGL(trsv_fwd_step, dim3(i < 0 ? 1 : nblocks - 1 - i), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks);
   } else {
     for (int i = nblocks; i >= 1; --i)
-      hipLaunchKernelGGL(trsv_bwd_step, dim3(i == nblocks ? 1 : i), dim3(64), 0, st, L, lda, inv_diag, b, i, nblocks);
+      hipLaunchKernelGGL(trsv_bwd_step, dim3(i == nblocks ? 1 : i), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks);
   }
   return hipGetLastError();
 }

@@ -157,6 +157,10 @@ int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, doubl
  * the inverses of the diagonal blocks.  info_host: 0, or 1-based index of the failing pivot. */
 int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra, double* inv_diag_dev, int* info_host);
 
+/* Process-wide tuning of the Cholesky schedule; value 0 restores the default.  Keys: "panel_width" (64 | 128),
+ * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update). */
+int gprx_set_tuning(const char* key, int value);
+
 /* measured back-to-back v_mfma_f64_16x16x4_f64 rate of the whole chip, TFLOP/s */
 int gprx_mfma_f64_peak(int device, double* tflops);
 

@@ -138,3 +138,32 @@ def test_potrf_reports_failing_pivot(lib):
     assert rc == _lib.GPRX_ENOTPD and info.value == 71
     with pytest.raises(np.linalg.LinAlgError):
         check(rc)
+
+
+@pytest.mark.parametrize("panel,outer,tile", [(64, 256, 0), (128, 128, 128), (64, 512, 64), (128, 256, 64)])
+def test_potrf_large_every_schedule(lib, panel, outer, tile):
+    """N = 2048 under several schedules, repeated: catches ordering races that small grids hide (every
+    workgroup of a panel launch re-reads the diagonal block, so it must not be overwritten in place
+    during that launch; the bulk trailing update runs on a second stream)."""
+    n, extra = 2048, 64
+    rng = np.random.default_rng(1)
+    g = rng.standard_normal((n, 96))
+    spd = g @ g.T / 96 + np.eye(n)
+    rhs = rng.standard_normal((extra, n))
+    L_ref = cholesky(spd, lower=True)
+    full = np.vstack([spd, rhs])
+    try:
+        for key, val in ((b"panel_width", panel), (b"outer_block", outer), (b"update_tile", tile)):
+            check(lib.gprx_set_tuning(key, val))
+        for _ in range(3):
+            dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
+            info = C.c_int(0)
+            check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
+            out = dA.to_array((n + extra, n))
+            assert rel_err(np.tril(out[:n]), L_ref) < 1e-11
+            assert rel_err(out[n:], solve_triangular(L_ref, rhs.T, lower=True).T) < 1e-11
+            dA.free()
+            dI.free()
+    finally:
+        for key in (b"panel_width", b"outer_block", b"update_tile"):
+            lib.gprx_set_tuning(key, 0)
