@@ -32,7 +32,8 @@ struct GemmArgs {
   int flags;
   int tiles_n;
   int tiles_m;
-  int nwg;  // launched workgroups (only tiles that touch the lower triangle when C_LOWER)
+  int nwg;  // launched workgroups per batch entry (only tiles that touch the lower triangle when C_LOWER)
+  int64_t strideA, strideB, strideC;  // element strides between batch entries (blockIdx.y)
 };
 
 constexpr int GEMM_BK = 16;
@@ -115,8 +116,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
   // each XCD a contiguous run of tiles: neighbours share operand panels in that XCD's L2), then, for
   // C_LOWER, decode the linear index over the lower trapezoid only -- every launched workgroup has
   // work, and the tiles are spread evenly over the XCDs.
+  p.A += (int64_t)blockIdx.y * p.strideA;
+  p.B += (int64_t)blockIdx.y * p.strideB;
+  p.C += (int64_t)blockIdx.y * p.strideC;
   int bid = blockIdx.x;
-  {
+  if (!(p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER))) {
+    // (with triangular operands the K range, i.e. the cost, varies along the tile order: keep the
+    // hardware's round-robin there, which spreads long and short tiles over all XCDs)
     const int q = p.nwg >> 3, rr = p.nwg & 7, xcd = bid & 7, k = bid >> 3;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
   }
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
 }
 
 template <int TA, int TB, int BM, int BN>
-inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p) {
+inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
@@ -295,25 +301,26 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p) {
   } else {
     p.nwg = p.tiles_m * p.tiles_n;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(p.nwg), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(p.nwg, batch), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 
 // tile: 0 = choose, 128 or 64 (square workgroup tiles)
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
-                              const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0) {
-  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0};
-  if (M <= 0 || N <= 0) return hipSuccess;
+                              const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0, int batch = 1,
+                              int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0) {
+  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC};
+  if (M <= 0 || N <= 0 || batch <= 0) return hipSuccess;
   if (tile == 0) {
     // 128 x 128 tiles (2 workgroups per CU) once they fill the chip more than twice over; otherwise
     // 64 x 64 tiles (4 per CU), which keep the tail short on the small updates of a factorisation
-    const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_C_LOWER) ? 2 : 1);
+    const int64_t t128 = (int64_t)batch * ((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_C_LOWER) ? 2 : 1);
     tile = (t128 >= 1024) ? 128 : 64;
   }
 #define GPRX_GEMM_CASE(TA_, TB_)                                                  \
   if (ta == TA_ && tb == TB_) {                                                   \
-    if (tile == 128) return launch_gemm_t<TA_, TB_, 128, 128>(st, p);             \
-    return launch_gemm_t<TA_, TB_, 64, 64>(st, p);                                \
+    if (tile == 128) return launch_gemm_t<TA_, TB_, 128, 128>(st, p, batch);      \
+    return launch_gemm_t<TA_, TB_, 64, 64>(st, p, batch);                         \
   }
   GPRX_GEMM_CASE(0, 1)
   GPRX_GEMM_CASE(0, 0)

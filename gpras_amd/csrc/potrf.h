@@ -451,6 +451,18 @@ struct PotrfProfile {
   }
 };
 
+// run-time tuning knobs (gprx_set_tuning): 0 = default heuristics
+struct PotrfTuning {
+  int panel_width = 0;   // 64 or 128
+  int outer_block = 0;   // multiple of 128
+  int update_tile = 0;   // tile of the TAIL GEMM: 64 or 128
+  int no_lookahead = 0;  // 1: everything on the main stream (debugging)
+};
+inline PotrfTuning& potrf_tuning() {
+  static PotrfTuning t;
+  return t;
+}
+
 // Streams and events of the look-ahead schedule (owned by the caller, reused across factorisations).
 struct PotrfStreams {
   hipStream_t aux = nullptr;
@@ -488,18 +500,6 @@ struct PotrfStreams {
 //                flops), overlapping the next block's panel chain on the main stream.
 // Order: TAIL(J) waits for HEAD(J) to be enqueued behind block J (event) and follows TAIL(J-1)
 // (stream order); HEAD(J) waits for TAIL(J-1), the last writer of the next block's columns.
-// run-time tuning knobs (gprx_set_tuning): 0 = default heuristics
-struct PotrfTuning {
-  int panel_width = 0;   // 64 or 128
-  int outer_block = 0;   // multiple of 128
-  int update_tile = 0;   // tile of the TAIL GEMM: 64 or 128
-  int no_lookahead = 0;  // 1: everything on the main stream (debugging)
-};
-inline PotrfTuning& potrf_tuning() {
-  static PotrfTuning t;
-  return t;
-}
-
 // diag_stage: scratch of np * 128 doubles (staged diagonal blocks, see potrf_panel_kernel)
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
                               double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr) {

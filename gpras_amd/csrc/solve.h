@@ -151,25 +151,37 @@ __global__ __launch_bounds__(256) void scatter_inv_diag(const double* __restrict
   }
 }
 
-inline hipError_t trtri_rec(hipStream_t st, const double* L, int64_t lda, double* X, int64_t ldx, double* T, int64_t ldt, int n) {
-  if (n == NB) return hipSuccess;
-  const int n1 = (n / NB / 2) * NB, n2 = n - n1;
-  hipError_t e = trtri_rec(st, L, lda, X, ldx, T, ldt, n1);
-  if (e != hipSuccess) return e;
-  e = trtri_rec(st, L + (int64_t)n1 * lda + n1, lda, X + (int64_t)n1 * ldx + n1, ldx, T + (int64_t)n1 * ldt + n1, ldt, n2);
-  if (e != hipSuccess) return e;
-  // T21 = L21 X11   (X11 lower triangular)
-  e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L + (int64_t)n1 * lda, lda, X, ldx, 0.0, T + (int64_t)n1 * ldt, ldt, GEMM_B_LOWER);
-  if (e != hipSuccess) return e;
-  // X21 = -X22 T21  (X22 lower triangular)
-  return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X + (int64_t)n1 * ldx + n1, ldx, T + (int64_t)n1 * ldt, ldt, 0.0,
-                     X + (int64_t)n1 * ldx, ldx, GEMM_A_LOWER);
-}
-
+// Bottom-up doubling: at level s (64, 128, ...) adjacent diagonal blocks X11, X22 of size s are already
+// inverted; X21 = -X22 (L21 X11) for all pairs at once (batched GEMMs: two launches per level instead of
+// two per tree node).  A ragged last pair (n not a multiple of 2 s) gets its own launches.
 inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* X, int64_t ldx, double* T,
                               int64_t ldt, int np) {
   hipLaunchKernelGGL(scatter_inv_diag, dim3(np / NB), dim3(256), 0, st, inv_diag, X, ldx);
-  return trtri_rec(st, L, lda, X, ldx, T, ldt, np);
+  for (int s = NB; s < np; s *= 2) {
+    const int full = np / (2 * s);            // pairs with two complete blocks
+    const int rem = np - full * 2 * s;        // leftover columns/rows after the complete pairs
+    auto level = [&](int off, int n1, int n2, int batch) -> hipError_t {
+      // blocks start at `off`; pair i covers [off + 2 s i, off + 2 s i + n1 + n2)
+      const int64_t sa = (int64_t)2 * s * lda + 2 * s, sx = (int64_t)2 * s * ldx + 2 * s, stt = (int64_t)2 * s * ldt + 2 * s;
+      const double* L21 = L + (int64_t)(off + n1) * lda + off;
+      double* X11 = X + (int64_t)off * ldx + off;
+      double* X22 = X + (int64_t)(off + n1) * ldx + (off + n1);
+      double* X21 = X + (int64_t)(off + n1) * ldx + off;
+      double* T21 = T + (int64_t)(off + n1) * ldt + off;
+      hipError_t e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L21, lda, X11, ldx, 0.0, T21, ldt, GEMM_B_LOWER, 0, batch, sa, sx, stt);
+      if (e != hipSuccess) return e;
+      return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X22, ldx, T21, ldt, 0.0, X21, ldx, GEMM_A_LOWER, 0, batch, sx, stt, sx);
+    };
+    if (full > 0) {
+      hipError_t e = level(0, s, s, full);
+      if (e != hipSuccess) return e;
+    }
+    if (rem > s) {  // one more pair: a complete first block and a shorter second one
+      hipError_t e = level(full * 2 * s, s, rem - s, 1);
+      if (e != hipSuccess) return e;
+    }
+  }
+  return hipGetLastError();
 }
 
 // ---- reductions ----------------------------------------------------------------------------------

@@ -2,6 +2,7 @@ import ctypes as C, sys, numpy as np
 sys.path.insert(0, ".")
 lib = C.CDLL("tools/libgprx_stamps.so")
 n = 4096
+NP = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 rng = np.random.default_rng(0)
 g = rng.standard_normal((n, 64))
 a = np.ascontiguousarray(g @ g.T / 64 + np.eye(n))
@@ -14,7 +15,7 @@ lib.gprx_potrf.argtypes = [C.c_int, vp, C.c_int64, C.c_int64, C.c_int64, vp, C.P
 info = C.c_int(0)
 for rep in range(3):
     lib.gprx_memcpy_h2d(0, dA, a.ctypes.data_as(vp), a.nbytes)
-    rc = lib.gprx_potrf(0, dA, n, 64, n - 64, dI, C.byref(info))
+    rc = lib.gprx_potrf(0, dA, n, NP, n - NP, dI, C.byref(info))
     out = (C.c_ulonglong * 64)()
     lib.gprx_panel_stamps(out)
     s = np.array(out[:16], dtype=np.int64)
