@@ -146,18 +146,18 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: instrumented pass, HIP events around every launch ----
         check(lib.gprx_set_profiling(h, 1), h)
-        prof = (C.c_double * 5)()
-        acc = np.zeros(5)
+        prof = (C.c_double * 8)()
+        acc = np.zeros(8)
         reps = 3
         for _ in range(reps):
             fit_step()
             lib.gprx_last_profile(h, prof)
             acc += np.array(list(prof))
         check(lib.gprx_set_profiling(h, 0), h)
-        gemm_ms, gemm_launches, gemm_flops, panel_ms, panel_launches = acc / reps
+        gemm_ms, gemm_launches, gemm_flops, panel_ms, panel_launches, strip_ms, strip_launches, strip_flops = acc / reps
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "gprx::gemm_f64_kernel<0,1,*> (Cholesky trailing update, A22 -= L21 L21^T)",
+            "kernel": "gprx::gemm_f64_kernel<0,1,64,64> (Cholesky bulk trailing update A22 -= L21 L21^T, K = 256: HEAD + TAIL launches)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -168,6 +168,8 @@ def main():
             "avg_launch_us": 1e3 * gemm_ms / gemm_launches,
             "algorithmic_flops_per_fit": gemm_flops,
             "panel_kernel_avg_us": 1e3 * panel_ms / panel_launches,
+            "strip_kernel": {"launches_per_fit": strip_launches, "avg_launch_us": 1e3 * strip_ms / max(strip_launches, 1), "tflops": strip_flops / (strip_ms * 1e-3) / 1e12 if strip_ms else None},
+            "cholesky_flops_per_fit": N_TRAIN**3 / 3,
         }
         ms = (C.c_double * 4)()
         lib.gprx_last_timings(h, ms)

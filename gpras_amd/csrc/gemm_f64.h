@@ -34,6 +34,8 @@ struct GemmArgs {
   int tiles_m;
   int nwg;  // launched workgroups per batch entry (only tiles that touch the lower triangle when C_LOWER)
   int64_t strideA, strideB, strideC;  // element strides between batch entries (blockIdx.y)
+  int ksplit;                          // > 0: blockIdx.z takes K slice [z * ksplit, (z+1) * ksplit) and writes slab z of C
+  int64_t slab;                        // elements per slab
 };
 
 constexpr int GEMM_BK = 16;
@@ -151,6 +153,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
   if (p.flags & GEMM_A_UPPER) kbeg = max(kbeg, m0);
   if (p.flags & GEMM_B_LOWER) kbeg = max(kbeg, n0);
   if (p.flags & GEMM_B_UPPER) kend = min(kend, n0 + BN);
+  if (p.ksplit > 0) {
+    kbeg = max(kbeg, (int)blockIdx.z * p.ksplit);
+    kend = min(kend, ((int)blockIdx.z + 1) * p.ksplit);
+    p.C += (int64_t)blockIdx.z * p.slab;
+  }
   kbeg &= ~(GEMM_BK - 1);
   kend = (kend + GEMM_BK - 1) & ~(GEMM_BK - 1);
   if (kend > p.K) kend = p.K;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
 }
 
 template <int TA, int TB, int BM, int BN>
-inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch) {
+inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nsplit = 1) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
@@ -301,7 +308,108 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch) {
   } else {
     p.nwg = p.tiles_m * p.tiles_n;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(p.nwg, batch), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+// ---- single-stage K = 64 update: C(M x N) -= A(M x 64) * B(N x 64)^T on the lower trapezoid -----------
+// The in-block "strip" updates of the Cholesky sit on its critical path and are pure latency: with K = 64
+// the whole operand panel of a 64 x 64 tile is 2 x 32 KiB, so every global load (operands and the C tile)
+// is issued before anything is waited for, followed by one barrier, 64 MFMAs per wave and the store.
+constexpr int S64_LD = 64 + 2;  // LDS row stride (doubles)
+
+__global__ __launch_bounds__(256) void syrk_k64_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
+                                                       int64_t lda, int64_t ldc, int M, int N, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) double sA[64 * S64_LD];
+  __shared__ __attribute__((aligned(16))) double sB[64 * S64_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
+  // lower-trapezoid tile decode (tiles are square: tile (ti, tj) has work iff tj <= ti)
+  int bid = blockIdx.x, ti, tj;
+  const int tri = tiles_n * (tiles_n + 1) / 2;
+  if (bid < tri) {
+    ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    while (ti * (ti + 1) / 2 > bid) --ti;
+    tj = bid - ti * (ti + 1) / 2;
+  } else {
+    const int rest = bid - tri;
+    ti = tiles_n + rest / tiles_n;
+    tj = rest % tiles_n;
+  }
+  const int m0 = ti * 64, n0 = tj * 64;
+  // operands: 64 rows x 32 chunks of 16 B each = 2048 chunks -> 8 per thread per operand
+  d2 ra[8], rb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q >> 5, cc = q & 31;
+    ra[i] = (m0 + row < M) ? *reinterpret_cast<const d2*>(A + (int64_t)(m0 + row) * lda + 2 * cc) : d2{0.0, 0.0};
+    rb[i] = (n0 + row < N) ? *reinterpret_cast<const d2*>(B + (int64_t)(n0 + row) * lda + 2 * cc) : d2{0.0, 0.0};
+  }
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = n0 + wn * 32 + b * 16 + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 32 + a * 16 + g + 4 * q;
+        acc[a][b][q] = (row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = tid + 256 * i;
+    const int row = q >> 5, cc = q & 31;
+    *reinterpret_cast<d2*>(sA + row * S64_LD + 2 * cc) = ra[i];
+    *reinterpret_cast<d2*>(sB + row * S64_LD + 2 * cc) = rb[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {  // 16 k per step; lane group g takes k = 16 ks + 4 g + j
+    double fa[2][4], fb[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const double* pa = sA + (wm * 32 + a * 16 + r) * S64_LD + 16 * ks + 4 * g;
+      const d2 lo = *reinterpret_cast<const d2*>(pa), hi = *reinterpret_cast<const d2*>(pa + 2);
+      fa[a][0] = -lo.x; fa[a][1] = -lo.y; fa[a][2] = -hi.x; fa[a][3] = -hi.y;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const double* pb = sB + (wn * 32 + b * 16 + r) * S64_LD + 16 * ks + 4 * g;
+      const d2 lo = *reinterpret_cast<const d2*>(pb), hi = *reinterpret_cast<const d2*>(pb + 2);
+      fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = n0 + wn * 32 + b * 16 + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = m0 + wm * 32 + a * 16 + g + 4 * q;
+        if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[a][b][q];
+      }
+    }
+}
+
+// C(M x N) -= A(M x 64) A(first N rows)^T, lower trapezoid only (M >= N)
+inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A, int64_t lda, double* C, int64_t ldc) {
+  const int tm = (M + 63) / 64;
+  int tn = (N + 63) / 64;
+  if (tm == 0 || tn == 0) return hipSuccess;
+  if (tn > tm) tn = tm;
+  const int nwg = tn * (tn + 1) / 2 + (tm - tn) * tn;
+  hipLaunchKernelGGL(syrk_k64_kernel, dim3(nwg), dim3(256), 0, st, A, A, C, lda, ldc, M, N, tn);
   return hipGetLastError();
 }
 
@@ -309,7 +417,7 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch) {
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0, int batch = 1,
                               int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0) {
-  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC};
+  GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC, 0, 0};
   if (M <= 0 || N <= 0 || batch <= 0) return hipSuccess;
   if (tile == 0) {
     // 128 x 128 tiles (2 workgroups per CU) once they fill the chip more than twice over; otherwise
@@ -327,6 +435,36 @@ inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int 
   GPRX_GEMM_CASE(1, 0)
 #undef GPRX_GEMM_CASE
   return hipErrorInvalidValue;
+}
+
+// ---- split-K for skinny products (few output tiles, long K) -------------------------------------------
+// out[i][j] = beta * out[i][j] + sum_z slab_z[i][j]   (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ ws, int nsplit, int M, int N, double beta,
+                                                            double* __restrict__ C, int64_t ldc) {
+  const int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (e >= (int64_t)M * N) return;
+  const int i = (int)(e / N), j = (int)(e % N);
+  double s = 0.0;
+  for (int z = 0; z < nsplit; ++z) s += ws[(int64_t)z * M * N + e];
+  double* cp = C + (int64_t)i * ldc + j;
+  *cp = (beta != 0.0) ? beta * (*cp) + s : s;
+}
+
+// C = alpha op(A) op(B) + beta C with K cut into slices of `kchunk` (multiple of 16) over blockIdx.z; ws must hold
+// ceil(K / kchunk) * M * N doubles.  No triangular flags.
+inline hipError_t launch_gemm_splitk(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
+                                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws, int kchunk) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int nsplit = (K + kchunk - 1) / kchunk;
+  GemmArgs p{A, B, ws, lda, ldb, (int64_t)N, M, N, K, alpha, 0.0, 0, 0, 0, 0, 0, 0, 0, kchunk, (int64_t)M * N};
+  hipError_t e = hipErrorInvalidValue;
+  if (ta == 0 && tb == 1) e = launch_gemm_t<0, 1, 64, 64>(st, p, 1, nsplit);
+  if (ta == 0 && tb == 0) e = launch_gemm_t<0, 0, 64, 64>(st, p, 1, nsplit);
+  if (ta == 1 && tb == 0) e = launch_gemm_t<1, 0, 64, 64>(st, p, 1, nsplit);
+  if (e != hipSuccess) return e;
+  const int64_t total = (int64_t)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)ws, nsplit, M, N, beta, C, ldc);
+  return hipGetLastError();
 }
 
 }  // namespace gprx

@@ -42,9 +42,8 @@ struct gprx_ctx {
   // data
   Buf X, Y, Z, invls, alpha, red, Kmat, invD, Xinv, Tmp, partial, xs, Ks, pred;
   // sparse path
-  Buf Xp, Zp, P, Am, Qm, Bm, invDL, invDB, SM, WP, WHP, WHQ, vecs, GPx, dZ, dstage;
+  Buf P, Am, Qm, Bm, invDL, invDB, SM, WP, WHP, WHQ, vecs, dZ, dstage, splitws;
   std::vector<double> yy;  // y.y per unit
-  int ldp = 0;
   double elbo_trAAT = 0.0;
   int* info = nullptr;
   // current factorisation
@@ -56,7 +55,7 @@ struct gprx_ctx {
   bool profiling = false;
   PotrfProfile prof;
   PotrfStreams pstreams;
-  double prof_out[6] = {0, 0, 0, 0, 0, 0};
+  double prof_out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -216,6 +215,16 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
     h->prof_out[2] = gemm_flops;
     h->prof_out[3] = panel_ms;
     h->prof_out[4] = (double)h->prof.panel_marks.size();
+    double strip_ms = 0.0, strip_flops = 0.0;
+    for (auto& mk : h->prof.strip_marks) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
+      strip_ms += ms;
+      strip_flops += mk.second;
+    }
+    h->prof_out[5] = strip_ms;
+    h->prof_out[6] = (double)h->prof.strip_marks.size();
+    h->prof_out[7] = strip_flops;
   }
   if (info != 0) {
     h->factorized = false;
@@ -273,13 +282,13 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
 //   P = Kuf (mp x np), Q = Kuu + jitter I -> L, A' = L^-1 P (unscaled: A = A' / sqrt(s)),
 //   B = I + A' A'^T / s -> LB, c = LB^-1 A' y / s (carried through the Cholesky as an appended row).
 // SM holds nine mp x mp scratch matrices.
+constexpr int SPLITK_CHUNK = 256;
 enum { SM_BFULL = 0, SM_LINV, SM_LBINV, SM_QINV, SM_SINV, SM_R, SM_T1, SM_T2, SM_W, SM_GQ, SM_COUNT };
 
 double* sm(gprx_handle h, int slot) { return h->SM.p + (size_t)slot * h->mp * h->mp; }
 
 int sgpr_alloc(gprx_handle h) {
   const size_t mp = h->mp, np = h->np;
-  h->ldp = (int)round_up(h->d + 1, 8);
   int rc;
   if ((rc = ensure(h, h->Z, sizeof(double) * h->m * h->d))) return rc;
   if ((rc = ensure(h, h->P, sizeof(double) * mp * np))) return rc;
@@ -290,6 +299,8 @@ int sgpr_alloc(gprx_handle h) {
   if ((rc = ensure(h, h->invDB, sizeof(double) * mp * NB))) return rc;
   if ((rc = ensure_zeroed(h, h->vecs, sizeof(double) * (4 * mp + np)))) return rc;
   if ((rc = ensure(h, h->dstage, sizeof(double) * std::max(mp, np) * PW))) return rc;
+  // split-K slabs: K = np in slices of SPLITK_CHUNK, outputs up to mp x mp
+  if ((rc = ensure(h, h->splitws, sizeof(double) * ((np + SPLITK_CHUNK - 1) / SPLITK_CHUNK) * mp * mp))) return rc;
   return GPRX_OK;
 }
 
@@ -315,7 +326,12 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   HIPCHK(h, hipMemcpyAsync(h->Am.p, h->P.p, sizeof(double) * (size_t)mp * np, hipMemcpyDeviceToDevice, st));
   HIPCHK(h, trsm_lower_left(st, h->Qm.p, mp, h->invDL.p, h->Am.p, np, mp, np));
   // B = I + A' A'^T / s (all of it: the gradient needs the symmetric matrix)
-  HIPCHK(h, launch_gemm(st, 0, 1, mp, mp, np, 1.0 / s, h->Am.p, np, h->Am.p, np, 0.0, h->Bm.p, mp, 0));
+  if (mp <= 512 && np >= 4 * SPLITK_CHUNK) {
+    // (mp/64)^2 output tiles against K = np: cut K over workgroups, reduce the slabs in a fixed order
+    HIPCHK(h, launch_gemm_splitk(st, 0, 1, mp, mp, np, 1.0 / s, h->Am.p, np, h->Am.p, np, 0.0, h->Bm.p, mp, h->splitws.p, SPLITK_CHUNK));
+  } else {
+    HIPCHK(h, launch_gemm(st, 0, 1, mp, mp, np, 1.0 / s, h->Am.p, np, h->Am.p, np, 0.0, h->Bm.p, mp, 0));
+  }
   hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0);
   hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0, h->red.p + 2);
   if ((rc = ensure(h, h->SM, sizeof(double) * (size_t)SM_COUNT * mp * mp))) return rc;
@@ -324,7 +340,11 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   double* crow = h->Bm.p + (size_t)mp * mp;
   HIPCHK(h, hipMemsetAsync(crow, 0, sizeof(double) * (size_t)NB * mp, st));
   const double* yu = h->Y.p + (size_t)unit * h->np;
-  HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 1.0 / s, h->Am.p, np, yu, 1, 0.0, crow, 1, 0, 64));
+  if (np >= 4 * SPLITK_CHUNK) {
+    HIPCHK(h, launch_gemm_splitk(st, 0, 0, mp, 1, np, 1.0 / s, h->Am.p, np, yu, 1, 0.0, crow, 1, h->splitws.p, SPLITK_CHUNK));
+  } else {
+    HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 1.0 / s, h->Am.p, np, yu, 1, 0.0, crow, 1, 0, 64));
+  }
   HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info, h->dstage.p, nullptr, &h->pstreams));
   HIPCHK(h, hipEventRecord(h->ev[2], st));
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, crow, mp, h->red.p);
@@ -405,7 +425,12 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   // noise terms: |y - P^T m|^2 and tr(B^-1) = |LB^-1|_F^2
   HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, h->P.p, np, mvec, 1, 0.0, qvec, 1, 0, 64));
   hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1), dim3(256), 0, st, yu, (const double*)qvec, n, h->red.p + 4);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, h->red.p + 3);
+  {
+    const int nb = mp < 64 ? mp : 64;
+    double* part = h->vecs.p + 2 * mp;  // scratch inside the vector block
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, (const double*)part, nb, h->red.p + 3);
+  }
   std::vector<double> hs(2 * width), hz((size_t)m * d);
   double red[5];
   HIPCHK(h, hipMemcpyAsync(hs.data(), sums, sizeof(double) * 2 * width, hipMemcpyDeviceToHost, st));
@@ -500,8 +525,8 @@ int gprx_destroy(gprx_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
-                 &h->pred, &h->Xp, &h->Zp, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs,
-                 &h->GPx, &h->dZ, &h->dstage})
+                 &h->pred, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs, &h->dZ,
+                 &h->dstage, &h->splitws})
     if (b->p) hipFree(b->p);
   if (h->info) hipFree(h->info);
   for (auto& ev : h->ev)
@@ -625,9 +650,9 @@ int gprx_set_profiling(gprx_handle h, int enabled) {
   return GPRX_OK;
 }
 
-int gprx_last_profile(gprx_handle h, double* out5) {
-  if (!h || !out5) return fail(h, GPRX_EINVAL, "null argument");
-  for (int i = 0; i < 5; ++i) out5[i] = h->prof_out[i];
+int gprx_last_profile(gprx_handle h, double* out8) {
+  if (!h || !out8) return fail(h, GPRX_EINVAL, "null argument");
+  for (int i = 0; i < 8; ++i) out8[i] = h->prof_out[i];
   return GPRX_OK;
 }
 

@@ -266,8 +266,16 @@ struct Panel128Ctx {
   int bad;
 };
 
+// Operands of the trailing updates that were NOT needed by the next sub-panel: they are issued one
+// step later, interleaved with that step's scalar factorisation (MFMA pipe and VALU overlap; issued
+// back-to-back they would hold the wave for 64 cycles each, in order, before the factorisation starts).
+struct Deferred128 {
+  double fa[4][2];
+  double fb[8][2];
+};
+
 template <int P>
-__device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c) {
+__device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c, Deferred128& df) {
   constexpr int C0 = 8 * P;
   constexpr int KT = C0 / 16;
   constexpr int HALF = P & 1;
@@ -283,15 +291,30 @@ __device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c) {
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int k = 0; k <= j; ++k) l[j][k] = c.sIn[(C0 + j) * PSUB + k];
+  const double own0 = c.sIn[c.tid * PSUB + 0], own1 = c.sIn[c.tid * PSUB + 1], own2 = c.sIn[c.tid * PSUB + 2],
+               own3 = c.sIn[c.tid * PSUB + 3], own4 = c.sIn[c.tid * PSUB + 4], own5 = c.sIn[c.tid * PSUB + 5],
+               own6 = c.sIn[c.tid * PSUB + 6], own7 = c.sIn[c.tid * PSUB + 7];
+  const double own[8] = {own0, own1, own2, own3, own4, own5, own6, own7};
+  // deferred updates of the previous step: tile columns right of the one this step has just consumed
+  if constexpr (P >= 1) {
+    constexpr int KD0 = (8 * (P - 1) + 8) / 16 + 1;  // first deferred tile column of step P - 1
+#pragma unroll
+    for (int kt = KD0; kt < 8; ++kt)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(df.fa[rt][0], df.fb[kt][0], acc[rt][kt], 0, 0, 0);
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(df.fa[rt][1], df.fb[kt][1], acc[rt][kt], 0, 0, 0);
+      }
+  }
+  int bad = c.bad;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     double s = l[j][j];
 #pragma unroll
     for (int m = 0; m < j; ++m) s = __builtin_fma(-l[j][m], l[j][m], s);
-    if (!(s > 0.0)) {
-      if (c.bad == 0) c.bad = C0 + j + 1;
-      s = 1.0;
-    }
+    const bool ok = s > 0.0;
+    bad = (!ok && bad == 0) ? C0 + j + 1 : bad;
+    s = ok ? s : 1.0;
     const double ri = rsqrt_f64(s);
     rinv[j] = ri;
     l[j][j] = s * ri;
@@ -303,13 +326,24 @@ __device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c) {
       l[i][j] = t * ri;
     }
   }
+  c.bad = bad;
   double x[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    double t = c.sIn[c.tid * PSUB + k];
+    double t = own[k];
 #pragma unroll
     for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], l[k][m], t);
     x[k] = (C0 + k > c.zero_above) ? 0.0 : t * rinv[k];
+  }
+  if constexpr (P >= 1) {
+    // one MFMA, then a run of VALU instructions, repeated: keeps the matrix pipe fed without stalling the chain
+    constexpr int KD0 = (8 * (P - 1) + 8) / 16 + 1;
+    constexpr int NM = (8 - KD0) * 8;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NM >= 40 ? 6 : (NM >= 24 ? 10 : 16), 0);
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) c.sX[c.tid * PSUB + k] = x[k];
@@ -329,21 +363,21 @@ __device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c) {
   __syncthreads();
   if constexpr (C0 + 8 < PW) {
     constexpr int KT0 = (C0 + 8) / 16;
-    double fa[4][2];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -c.sX[(64 * c.wave + 16 * rt + c.r) * PSUB + 4 * ks + c.g];
+      for (int ks = 0; ks < 2; ++ks) df.fa[rt][ks] = -c.sX[(64 * c.wave + 16 * rt + c.r) * PSUB + 4 * ks + c.g];
 #pragma unroll
     for (int kt = KT0; kt < 8; ++kt) {
       const int kk = kt * 16 + c.r;
-      const double fb0 = (kk >= C0 + 8) ? c.sX[kk * PSUB + c.g] : 0.0;
-      const double fb1 = (kk >= C0 + 8) ? c.sX[kk * PSUB + 4 + c.g] : 0.0;
+      df.fb[kt][0] = (kk >= C0 + 8) ? c.sX[kk * PSUB + c.g] : 0.0;
+      df.fb[kt][1] = (kk >= C0 + 8) ? c.sX[kk * PSUB + 4 + c.g] : 0.0;
+    }
+    // only the tile column that the next sub-panel reads is updated now
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb0, acc[rt][kt], 0, 0, 0);
-        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb1, acc[rt][kt], 0, 0, 0);
-      }
+    for (int rt = 0; rt < 4; ++rt) {
+      acc[rt][KT0] = __builtin_amdgcn_mfma_f64_16x16x4f64(df.fa[rt][0], df.fb[KT0][0], acc[rt][KT0], 0, 0, 0);
+      acc[rt][KT0] = __builtin_amdgcn_mfma_f64_16x16x4f64(df.fa[rt][1], df.fb[KT0][1], acc[rt][KT0], 0, 0, 0);
     }
   }
 }
@@ -408,22 +442,23 @@ __global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict_
       }
     }
 
-  panel128_step<0>(acc, c);
-  panel128_step<1>(acc, c);
-  panel128_step<2>(acc, c);
-  panel128_step<3>(acc, c);
-  panel128_step<4>(acc, c);
-  panel128_step<5>(acc, c);
-  panel128_step<6>(acc, c);
-  panel128_step<7>(acc, c);
-  panel128_step<8>(acc, c);
-  panel128_step<9>(acc, c);
-  panel128_step<10>(acc, c);
-  panel128_step<11>(acc, c);
-  panel128_step<12>(acc, c);
-  panel128_step<13>(acc, c);
-  panel128_step<14>(acc, c);
-  panel128_step<15>(acc, c);
+  Deferred128 df;
+  panel128_step<0>(acc, c, df);
+  panel128_step<1>(acc, c, df);
+  panel128_step<2>(acc, c, df);
+  panel128_step<3>(acc, c, df);
+  panel128_step<4>(acc, c, df);
+  panel128_step<5>(acc, c, df);
+  panel128_step<6>(acc, c, df);
+  panel128_step<7>(acc, c, df);
+  panel128_step<8>(acc, c, df);
+  panel128_step<9>(acc, c, df);
+  panel128_step<10>(acc, c, df);
+  panel128_step<11>(acc, c, df);
+  panel128_step<12>(acc, c, df);
+  panel128_step<13>(acc, c, df);
+  panel128_step<14>(acc, c, df);
+  panel128_step<15>(acc, c, df);
   if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
 }
 
@@ -431,7 +466,8 @@ __global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict_
 struct PotrfProfile {
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  std::vector<std::pair<size_t, double>> gemm_marks;  // (index of start event, algorithmic flops of the launch)
+  std::vector<std::pair<size_t, double>> gemm_marks;   // bulk updates (HEAD / TAIL): (index of start event, algorithmic flops)
+  std::vector<std::pair<size_t, double>> strip_marks;  // K = 64 strip updates inside an outer block
   std::vector<size_t> panel_marks;
   hipEvent_t next() {
     if (used == pool.size()) {
@@ -444,6 +480,7 @@ struct PotrfProfile {
   void reset() {
     used = 0;
     gemm_marks.clear();
+    strip_marks.clear();
     panel_marks.clear();
   }
   ~PotrfProfile() {
@@ -506,11 +543,11 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   const double* prev_stage = nullptr;
   double* prev_dst = nullptr;
   int prev_pw = 0;
-  auto mark_gemm = [&](hipStream_t s, int ncols_lower, int rows_rect, int ncols, int k) {
+  auto mark_gemm = [&](hipStream_t s, int ncols_lower, int rows_rect, int ncols, int k, bool strip = false) {
     if (!prof) return;
     // algorithmic flops: 2 K per updated element (lower triangle incl. diagonal of the square part + rectangle)
     const double elems = 0.5 * (double)ncols_lower * (ncols_lower + 1) + (double)rows_rect * ncols;
-    prof->gemm_marks.push_back({prof->used, 2.0 * k * elems});
+    (strip ? prof->strip_marks : prof->gemm_marks).push_back({prof->used, 2.0 * k * elems});
     hipEventRecord(prof->next(), s);
   };
   auto mark_end = [&](hipStream_t s) {
@@ -551,8 +588,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       if (strip > 0) {
         double* L21 = A + (int64_t)(c + pw) * lda + c;
         double* A22 = A + (int64_t)(c + pw) * lda + (c + pw);
-        mark_gemm(st, strip, rows_below - strip, strip, pw);
-        hipError_t e = launch_gemm(st, 0, 1, rows_below, strip, pw, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64);
+        mark_gemm(st, strip, rows_below - strip, strip, pw, true);
+        hipError_t e = (pw == NB) ? launch_syrk_k64(st, rows_below, strip, L21, lda, A22, lda)
+                                  : launch_gemm(st, 0, 1, rows_below, strip, pw, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64);
         mark_end(st);
         if (e != hipSuccess) return e;
       }

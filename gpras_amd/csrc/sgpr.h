@@ -22,18 +22,26 @@ __global__ __launch_bounds__(256) void diag_sum_kernel(const double* B, int64_t 
   if (threadIdx.x == 0) out[0] = s[0] + s[1] + s[2] + s[3];
 }
 
-// out[0] = sum of squares of the (rows x cols) matrix (single workgroup: deterministic)
-__global__ __launch_bounds__(256) void sumsq_kernel(const double* A, int64_t ld, int rows, int cols, double* out) {
+// partial[b] = sum of squares of the rows handled by workgroup b (row-strided); a second launch with one
+// workgroup adds the partials in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const double* A, int64_t ld, int rows, int cols, double* partial) {
   __shared__ double s[4];
   double a = 0.0;
-  for (int64_t e = threadIdx.x; e < (int64_t)rows * cols; e += 256) {
-    const double v = A[(e / cols) * ld + (e % cols)];
-    a = __builtin_fma(v, v, a);
-  }
+  for (int r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      const double v = A[(int64_t)r * ld + c];
+      a = __builtin_fma(v, v, a);
+    }
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = s[0] + s[1] + s[2] + s[3];
+  if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(64) void sum_partials_kernel(const double* partial, int n, double* out) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) a += partial[i];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) out[0] = a;
 }
 
 // out[0] = sum_{i<n} (y[i] - q[i])^2

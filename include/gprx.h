@@ -110,10 +110,11 @@ int gprx_last_timings(gprx_handle h, double* ms4);
 /* Per-launch timing of the Cholesky's two kernels (exact path), for bench.py's roofline line.
  * With profiling enabled every gprx_factorize / gprx_objective brackets each launch with HIP events
  * on the handle's stream (this perturbs the run slightly: keep it off inside timed regions).
- * gprx_last_profile: out5 = [trailing-update GEMM total ms, launches, algorithmic flops,
- *                           panel kernel total ms, launches] of the last exact factorisation. */
+ * gprx_last_profile: out8 = [bulk trailing-update GEMM (gemm_f64_kernel<0,1,..>) total ms, launches,
+ *                           algorithmic flops, panel kernel total ms, launches, K=64 strip kernel total ms,
+ *                           launches, algorithmic flops] of the last exact factorisation. */
 int gprx_set_profiling(gprx_handle h, int enabled);
-int gprx_last_profile(gprx_handle h, double* out5);
+int gprx_last_profile(gprx_handle h, double* out8);
 
 /* ---- batched small problems ------------------------------------------------------- */
 /* Evaluate loss (+ gradient) for `count` units in one call: units[i] with theta row i

@@ -1,0 +1,112 @@
+"""Edge cases of the path on the GPU: ragged and tiny sizes, wide feature vectors, many units, empty
+predict batches, prediction tiles larger than one pass, duplicated inputs."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpras_amd import _lib
+from gpras_amd._lib import check, ptr
+from gpras_amd.gpr import GPRAS
+from gpras_amd.synth import make_regression
+from oracle import exact as oex
+from oracle import kernels as okn
+from oracle import sgpr as osg
+from oracle import transforms as otr
+
+pytestmark = pytest.mark.gpu
+
+
+def theta_of(variance, ls, noise):
+    wv, wl, wn = otr.unconstrain(variance, ls, noise)
+    return np.ascontiguousarray(np.concatenate([[wv], np.atleast_1d(wl), [wn]]))
+
+
+@pytest.mark.parametrize("n,d,m", [(3, 1, 0), (63, 2, 0), (65, 3, 0), (129, 12, 0), (200, 50, 0), (70, 2, 1), (130, 7, 65), (100, 3, 100), (50, 4, 64)])
+def test_ragged_sizes_exact_and_sparse(lib, n, d, m):
+    """Sizes around the 64-padding granule, d up to 50 (the reference sweeps 1..50 modes), M = 1, M = N, M > N."""
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=7, config=5, unit=n + d + m)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, m, okn.KERNEL_IDS["Matern52"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    try:
+        variance, ls, noise = 0.9, 1.1, 0.2
+        theta = theta_of(variance, ls, noise)
+        z = None
+        if m:
+            rng = np.random.default_rng(m)
+            z = np.ascontiguousarray(x[rng.integers(0, n, size=m)] + 0.05 * rng.standard_normal((m, d)))
+        loss = C.c_double()
+        grad = np.zeros(3 + m * d)
+        check(lib.gprx_objective(h, 0, ptr(theta), ptr(z) if m else None, 15 if m else 7, C.byref(loss), ptr(grad)), h)
+        if m:
+            ref_loss, g = osg.loss_and_grad("Matern52", x, y[:, 0], z, theta[0], float(theta[1]), theta[2])
+            ref = np.concatenate([[g["variance"], g["lengthscales"], g["noise"]], g["Z"].ravel()])
+            ref_mean, ref_var = osg.predict("Matern52", x, y[:, 0], z, variance, ls, noise, xs)
+        else:
+            ref_loss, g = oex.loss_and_grad("Matern52", x, y[:, 0], theta[0], float(theta[1]), theta[2])
+            ref = np.array([g["variance"], g["lengthscales"], g["noise"]])
+            ref_mean, ref_var = oex.predict("Matern52", x, y[:, 0], variance, ls, noise, xs)
+        assert abs(loss.value - ref_loss) <= 1e-9 * abs(ref_loss)
+        assert np.max(np.abs(grad - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref)))
+        mean, var = np.zeros(7), np.zeros(7)
+        check(lib.gprx_predict(h, ptr(xs), 7, ptr(mean), ptr(var), 1), h)
+        assert np.max(np.abs(mean - ref_mean)) <= 1e-8 * max(np.max(np.abs(ref_mean)), 1e-3)
+        assert np.max(np.abs(var - ref_var) / ref_var) <= 1e-8
+        # empty batch is a no-op, not an error
+        assert lib.gprx_predict(h, None, 0, None, None, 1) == _lib.GPRX_OK
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_predict_tiling_and_latent_variance(lib):
+    """More test points than one 8192-column pass; include_noise = 0 gives predict_f."""
+    n, d, ns = 300, 3, 8192 + 8192 + 77
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=ns, config=5, unit=1)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    try:
+        theta = theta_of(1.0, 0.8, 0.1)
+        loss = C.c_double()
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss)), h)
+        mean, var, varf = np.zeros(ns), np.zeros(ns), np.zeros(ns)
+        check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(var), 1), h)
+        check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(varf), 0), h)
+        ref_mean, ref_var = oex.predict("RBF", x, y[:, 0], 1.0, 0.8, 0.1, xs, include_noise=True)
+        assert np.max(np.abs(mean - ref_mean)) <= 1e-8 * np.max(np.abs(ref_mean))
+        assert np.max(np.abs(var - ref_var) / ref_var) <= 1e-8
+        assert np.allclose(var - varf, 0.1, rtol=0, atol=1e-12)
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_many_units_share_one_handle():
+    """K = 12 output columns (spatial modes) through the class: one handle, unit-major y on the device."""
+    x, y, xs = make_regression(150, 4, n_outputs=12, n_test=9, config=5, unit=2)
+    g = GPRAS("RBF")
+    g.fit(x, y, 10, "grid", "adam", max_iter=2)
+    mean, var = g.predict(xs)
+    assert mean.shape == (9, 12) and var.shape == (9, 12)
+    for u in (0, 5, 11):
+        m = g.models[u]
+        rm, rv = osg.predict("RBF", x, y[:, u], m.Z, m.variance, m.lengthscales, m.noise, xs)
+        assert np.allclose(mean[:, u], rm, rtol=1e-8, atol=1e-10) and np.allclose(var[:, u], rv, rtol=1e-8)
+
+
+def test_duplicate_training_points_need_the_noise_term():
+    """Exact GP on duplicated inputs: K is singular without s I; tiny noise must still factor or raise LinAlgError."""
+    x, y, _ = make_regression(64, 2, config=5, unit=3)
+    x2 = np.vstack([x, x])
+    y2 = np.vstack([y, y])
+    g = GPRAS("RBF")
+    g._init_models(x2.astype(np.float64), y2.astype(np.float64), None)
+    g.models[0].assign(noise=1e-3)
+    assert np.isfinite(g.models[0].training_loss())
+    g.models[0].w_noise = -1e3  # softplus underflows: noise = 1e-6 + 0 -> Cholesky may fail; must be an exception, not garbage
+    try:
+        val = g.models[0].training_loss()
+        assert np.isfinite(val)
+    except np.linalg.LinAlgError:
+        pass
