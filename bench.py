@@ -41,6 +41,17 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz: half th
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be read
+    inside this process); None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,7 +174,7 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic("gemm_f64_kernel<0,1,64,64>"),
             "launches_per_fit": gemm_launches,
             "avg_launch_us": 1e3 * gemm_ms / gemm_launches,
             "algorithmic_flops_per_fit": gemm_flops,
@@ -212,6 +223,21 @@ def main():
         extra["F3_lbfgs50_matern52_ard_seconds"] = t3
         extra["F3_evaluations"] = g3.models[0].n_evals
         extra["F3_fits_per_s"] = 1.0 / t3
+        # sparse model at a reference-realistic size (gpras example config: 10 modes, 50 inducing points; gpr.py:299):
+        # SGPR.training_loss + gradient evaluations, and the reference's default fit (two-stage Adam, 100 + 100 steps)
+        n_s, d_s, m_s = 4096, 10, 50
+        xsp, ysp, _ = make_regression(n_s, d_s, n_outputs=1, n_test=0, config=6, unit=0)
+        gs = GPRAS("RBF", device=device)
+        gs._init_models(xsp, ysp, m_s, "kmeans")
+        ms_model = gs.models[0]
+        ms_model.loss_and_grad()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            ms_model.loss_and_grad()
+        extra["sgpr_n4096_d10_m50_loss_grad_evals_per_s"] = 20 / (time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
+        extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
         result["extra"] = extra
 
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----
