@@ -53,6 +53,7 @@ class GPRAS:
         self.x: NDArray[Any] | None = None
         self.y: NDArray[Any] | None = None
         self.engine: Engine | None = None
+        self.engines: list[Engine] = []
         self.ard = False
 
     def fit(
@@ -63,15 +64,32 @@ class GPRAS:
         inducing_initializer: InductionInitializerType = "kmeans",
         optimization_method: OptimizerType = "two-stage",
         ard: bool = False,
+        workers: int = 1,
         **opt_kwargs: Any,
     ) -> None:
-        """Fit one GP per column of ``y`` (gpr.py:237-275)."""
+        """Fit one GP per column of ``y`` (gpr.py:237-275).
+
+        ``workers > 1`` (extension): the per-mode loop, serial in the reference (gpr.py:272-274), runs from
+        that many host threads, each with its own engine (handle + HIP stream) on the same GPU, so the many
+        small launches of different modes overlap on the device.  Results per mode are unchanged.
+        """
         self.x = x.astype(np.float64)
         self.y = y.astype(np.float64)
-        self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard)
-        opt = OPTIMIZERS[optimization_method]
-        for _, model in enumerate(self.models):
-            opt(model, **opt_kwargs)
+        opt = OPTIMIZERS[optimization_method]  # KeyError before any device work, as the reference (gpr.py:272)
+        self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard, workers=workers)
+        if len(self.engines) == 1:
+            for _, model in enumerate(self.models):
+                opt(model, **opt_kwargs)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(worker: int) -> None:
+            for model in self.models[worker :: len(self.engines)]:
+                opt(model, **opt_kwargs)
+
+        with ThreadPoolExecutor(max_workers=len(self.engines)) as pool:
+            for fut in [pool.submit(run, w) for w in range(len(self.engines))]:
+                fut.result()
 
     def _init_models(
         self,
@@ -80,16 +98,20 @@ class GPRAS:
         n_inducing: int | None,
         inducing_initializer: InductionInitializerType = "kmeans",
         ard: bool = False,
+        workers: int = 1,
     ) -> None:
         """Create one model per spatial mode using base model settings (gpr.py:277-308)."""
         inducing = None if n_inducing is None else self._create_inducing(x, n_inducing, inducing_initializer)
         ini_length = np.mean(abs(x))
         self.ard = bool(ard)
-        if self.engine is not None:
-            self.engine.close()
-        self.engine = Engine(self.kernel_str, x, y, 0 if inducing is None else inducing.shape[0], ard=self.ard, device=self.device)
+        for eng in getattr(self, "engines", []):
+            eng.close()
+        n_eng = max(1, min(int(workers), y.shape[1]))
+        m = 0 if inducing is None else inducing.shape[0]
+        self.engines = [Engine(self.kernel_str, x, y, m, ard=self.ard, device=self.device) for _ in range(n_eng)]
+        self.engine = self.engines[0]
         # variance 1, lengthscale mean|x| (gpr.py:289, :298); Gaussian likelihood variance 1.0 (gpflow default)
-        self.models = [GPModel(self.engine, i, inducing, 1.0, ini_length, 1.0) for i in range(y.shape[1])]
+        self.models = [GPModel(self.engines[i % n_eng], i, inducing, 1.0, ini_length, 1.0) for i in range(y.shape[1])]
 
     def _create_inducing(self, x: NDArray[Any], n_inducing: int, method: InductionInitializerType) -> NDArray[Any]:
         """Create an array representing locations in dataspace (gpr.py:310-320)."""

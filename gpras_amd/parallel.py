@@ -78,8 +78,8 @@ class ShardedGPRAS(GPRAS):
     def fit(self, x, y, n_inducing, inducing_initializer="kmeans", optimization_method="two-stage", ard: bool = False, **opt_kwargs: Any) -> None:
         self.x = x.astype(np.float64)
         self.y = y.astype(np.float64)
-        self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard)
         opt = OPTIMIZERS[optimization_method]
+        self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard)
         mine = shard_units(len(self.models), self.rank, self.world)
         for u in mine:
             opt(self.models[u], **opt_kwargs)

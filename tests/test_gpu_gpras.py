@@ -78,3 +78,24 @@ def test_errors_surface_as_python_exceptions():
     g.models[0].Z = np.repeat(x[:1], 8, axis=0)
     mean, var = g.predict(x[:4])
     assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var))
+
+
+def test_concurrent_workers_give_identical_models():
+    """workers > 1: modes fitted from several host threads / handles concurrently; per-mode results unchanged."""
+    import time
+
+    x, y, xs = make_regression(1500, 6, n_outputs=8, n_test=20, config=4, unit=5)
+    g1 = GPRAS("Matern32")
+    t0 = time.perf_counter()
+    g1.fit(x, y, 40, "grid", "adam", max_iter=30)
+    t1 = time.perf_counter() - t0
+    g4 = GPRAS("Matern32")
+    t0 = time.perf_counter()
+    g4.fit(x, y, 40, "grid", "adam", max_iter=30, workers=4)
+    t4 = time.perf_counter() - t0
+    for a, b in zip(g1.models, g4.models):
+        assert a.variance == b.variance and a.noise == b.noise and np.array_equal(a.Z, b.Z)
+    m1, v1 = g1.predict(xs)
+    m4, v4 = g4.predict(xs)
+    assert np.array_equal(m1, m4) and np.array_equal(v1, v4)
+    print(f"serial {t1:.3f} s, 4 workers {t4:.3f} s")
