@@ -48,6 +48,7 @@ struct gprx_ctx {
   int* info = nullptr;
   // current factorisation
   bool factorized = false;
+  bool have_linv = false;  // Xinv holds L^-1 of the current factorisation (exact path)
   int cur_unit = -1;
   double variance = 1.0, noise = 1.0;
   std::vector<double> ls;
@@ -233,6 +234,7 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
     return fail(h, GPRX_ENOTPD, msg);
   }
   h->factorized = true;
+  h->have_linv = false;
   h->cur_unit = unit;
   h->variance = t.variance;
   h->noise = t.noise;
@@ -251,6 +253,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   hipStream_t st = h->stream;
   HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0, sizeof(double) * h->np * ld, st));
   HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
+  h->have_linv = true;
   // K^-1 = X^T X, lower tiles, into Tmp
   HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld,
                         GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER));
@@ -712,7 +715,19 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   const int np = (int)h->np;
   const int64_t ld = h->np;
   const int tile = (int)std::min<int64_t>(PRED_TILE, round_up(ns, NB));
-  if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile))) return rc;
+  // Many test points: V = L^-1 Ks as ONE triangular GEMM per tile against the explicit inverse (computed once
+  // per factorisation, N^3/3 flops amortised over N* >= 2 N points) instead of the recursive solve's ~2 N/64
+  // dependent launches per tile.  Few points: blocked forward substitution on L itself.
+  const bool use_inverse = ns >= 2 * (int64_t)h->n;
+  if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile * (use_inverse ? 2 : 1)))) return rc;
+  double* Vbuf = h->Ks.p + (use_inverse ? (size_t)h->np * tile : 0);
+  if (use_inverse && !h->have_linv) {
+    if ((rc = ensure(h, h->Xinv, sizeof(double) * h->np * ld))) return rc;
+    if ((rc = ensure(h, h->Tmp, sizeof(double) * h->np * ld))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0, sizeof(double) * h->np * ld, st));
+    HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
+    h->have_linv = true;
+  }
   const int nchunks = (np + rows_per_chunk - 1) / rows_per_chunk;
   if ((rc = ensure(h, h->pred, sizeof(double) * (size_t)nchunks * tile))) return rc;
   const double base = h->variance + (include_noise ? h->noise : 0.0);
@@ -724,8 +739,12 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
     dim3 grid((ts + 255) / 256, nchunks);
     hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, h->alpha.p, np, ts, rows_per_chunk, h->pred.p);
     hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, 0, mean_dev + t0);
-    HIPCHK(h, trsm_lower_left(st, h->Kmat.p, ld, h->invD.p, h->Ks.p, tile, np, tsp));
-    hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, (const double*)nullptr, np, ts, rows_per_chunk,
+    if (use_inverse) {
+      HIPCHK(h, launch_gemm(st, 0, 0, np, tsp, np, 1.0, h->Xinv.p, ld, h->Ks.p, tile, 0.0, Vbuf, tile, GEMM_A_LOWER, 128));
+    } else {
+      HIPCHK(h, trsm_lower_left(st, h->Kmat.p, ld, h->invD.p, h->Ks.p, tile, np, tsp));
+    }
+    hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, (const double*)Vbuf, (int64_t)tile, (const double*)nullptr, np, ts, rows_per_chunk,
                        h->pred.p);
     hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, base, -1.0, 0, var_dev + t0);
   }

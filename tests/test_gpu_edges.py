@@ -82,6 +82,33 @@ def test_predict_tiling_and_latent_variance(lib):
         lib.gprx_destroy(h)
 
 
+def test_predict_inverse_path_matches_substitution(lib):
+    """N* >= 2 N switches predict to one triangular GEMM against the explicit inverse of L; N* < 2 N uses blocked
+    substitution.  Both must agree with the oracle (and hence with each other) on an ill-conditioned-ish K."""
+    n, d = 640, 4
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=2 * n + 50, config=5, unit=4)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    try:
+        variance, ls, noise = 2.0, 1.5, 1e-4  # cond(K) ~ 1e7
+        theta = theta_of(variance, ls, noise)
+        loss = C.c_double()
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss)), h)
+        ns = xs.shape[0]
+        m_big, v_big = np.zeros(ns), np.zeros(ns)
+        check(lib.gprx_predict(h, ptr(xs), ns, ptr(m_big), ptr(v_big), 1), h)  # inverse path
+        m_small, v_small = np.zeros(100), np.zeros(100)
+        check(lib.gprx_predict(h, ptr(xs), 100, ptr(m_small), ptr(v_small), 1), h)  # substitution path
+        ref_m, ref_v = oex.predict("RBF", x, y[:, 0], variance, ls, noise, xs, True)
+        assert np.max(np.abs(m_big - ref_m)) <= 1e-8 * np.max(np.abs(ref_m))
+        assert np.max(np.abs(v_big - ref_v) / ref_v) <= 1e-8
+        assert np.max(np.abs(v_small - ref_v[:100]) / ref_v[:100]) <= 1e-8
+        assert np.max(np.abs(v_big[:100] - v_small) / v_small) <= 1e-9
+    finally:
+        lib.gprx_destroy(h)
+
+
 def test_many_units_share_one_handle():
     """K = 12 output columns (spatial modes) through the class: one handle, unit-major y on the device."""
     x, y, xs = make_regression(150, 4, n_outputs=12, n_test=9, config=5, unit=2)
