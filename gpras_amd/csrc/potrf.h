@@ -505,10 +505,7 @@ struct PotrfStreams {
   hipStream_t aux = nullptr;
   hipEvent_t block_done = nullptr, tail_done = nullptr;
   hipError_t init() {
-    // lowest priority: the bulk TAIL updates must not take CUs from the panel chain on the main stream
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);
-    hipError_t e = hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, lo);
+    hipError_t e = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);  // normal priority (see gprx_create)
     if (e != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&block_done, hipEventDisableTiming)) != hipSuccess) return e;
     return hipEventCreateWithFlags(&tail_done, hipEventDisableTiming);

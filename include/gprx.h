@@ -96,6 +96,12 @@ int gprx_objective(gprx_handle h, int unit, const double* theta, const double* z
  * priors for the parameters in mask. */
 int gprx_factorize(gprx_handle h, int unit, const double* theta, const double* z, int mask, double* loss);
 
+/* Many independent cells on one GPU: factorise `count` exact models (one handle each, all on the caller's
+ * thread) by enqueueing every handle's work before waiting for any of them, so the latency-bound panel
+ * chains of different cells overlap on the device.  thetas: (count, n_theta); losses: count values.
+ * Replaces a Python loop of gprx_factorize calls; each handle is left factorised as by gprx_factorize. */
+int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const double* thetas, int mask, double* losses);
+
 /* SGPR.predict_y (gpr.py:336-339): predictive mean and variance at xs (ns, d) for the unit
  * factorised last.  include_noise != 0 adds the likelihood variance (predict_y); 0 gives
  * predict_f.  mean/var: ns values each. */
