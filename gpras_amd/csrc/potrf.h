@@ -32,13 +32,14 @@ __device__ unsigned long long g_panel_stamps[64];
 constexpr int PANEL_ROWS = 64;   // rows of A21 per workgroup (workgroup rows 64..127; rows 0..63 = the diagonal block)
 constexpr int PWG_ROWS = 128;    // rows held by one workgroup
 constexpr int PSUB = 9;          // LDS row stride of the 8-column sub-panel buffers (row-per-lane b64 access conflict-free)
-constexpr int POUT = NB + 1;     // LDS row stride of the output image
 
 // State shared by the unrolled sub-panel steps.
 struct PanelCtx {
   double* sIn;    // [128][9]  current sub-panel, as updated so far (written from the accumulators)
   double* sX;     // [128][9]  current sub-panel, solved (MFMA operands of the trailing update)
-  double* sOut;   // [128][65] all solved columns (coalesced store at the end)
+  double* out;    // this thread's output row (global memory or the diagonal-block staging area); nullptr: none
+  double* inv_diag;
+  int ident;      // >= 0: this thread carries identity row `ident` (last workgroup)
   int tid, wave, g, r;
   int zero_above;  // diagonal-block rows: entries right of the diagonal are zero
   int bad;
@@ -99,9 +100,16 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[2][4], PanelCtx& c) {
       x[k] = (C0 + k > c.zero_above) ? 0.0 : t * rinv[k];
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      c.sX[c.tid * PSUB + k] = x[k];
-      c.sOut[c.tid * POUT + C0 + k] = x[k];
+    for (int k = 0; k < 8; ++k) c.sX[c.tid * PSUB + k] = x[k];
+    // solved values leave through memory directly (64 contiguous bytes per row and sub-panel): no 66-KiB output
+    // image in LDS, so several panel workgroups -- of this or of other cells -- fit on one CU beside GEMM tiles
+    if (c.out) {
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) *reinterpret_cast<d2*>(c.out + C0 + k) = d2{x[k], x[k + 1]};
+    }
+    if (c.ident >= 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c.inv_diag[(C0 + k) * NB + c.ident] = x[k];  // identity row i -> column i of L11^-1
     }
   }
   if constexpr (P == 1) { PSTAMP(13) }
@@ -163,11 +171,10 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
                                                           double* __restrict__ prev_dst, int prev_pw) {
   __shared__ __attribute__((aligned(16))) double sIn[PWG_ROWS * PSUB];
   __shared__ __attribute__((aligned(16))) double sX[PWG_ROWS * PSUB];
-  __shared__ __attribute__((aligned(16))) double sOut[PWG_ROWS * POUT];
   PanelCtx c;
   c.sIn = sIn;
   c.sX = sX;
-  c.sOut = sOut;
+  c.inv_diag = inv_diag;
   c.tid = threadIdx.x;
   const int lane = c.tid & 63;
   c.wave = c.tid >> 6;
@@ -177,6 +184,19 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   c.bad = 0;
   const bool last = (int)blockIdx.x == nchunks;
   if (last) flush_staged_block(prev_stage, prev_dst, lda, prev_pw, c.tid);
+  // where this thread's solved row goes (threads 0..127 own workgroup rows 0..127)
+  c.out = nullptr;
+  c.ident = -1;
+  if (c.tid < NB) {
+    if (last) c.out = stage_out + c.tid * NB;  // the factored diagonal block is staged (in-place hazard, see above)
+  } else if (c.tid < PWG_ROWS) {
+    if (!last) {
+      const int idx = blockIdx.x * PANEL_ROWS + (c.tid - NB);
+      if (idx < rows_below) c.out = A + (int64_t)(NB + idx) * lda;
+    } else {
+      c.ident = c.tid - NB;
+    }
+  }
   PSTAMP(0)
 
   // ---- load straight into the accumulator layout (32 loads per lane, all in flight) ----
@@ -218,33 +238,8 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   panel_step<5>(acc, c);
   panel_step<6>(acc, c);
   panel_step<7>(acc, c);
-  __syncthreads();
   PSTAMP(4)
-
-  // ---- coalesced store from the output image: 128 rows x 32 chunks of 16 B ----
-  if (!last) {
-#pragma unroll
-    for (int i = 8; i < 16; ++i) {  // workgroup rows 64..127
-      const int q = c.tid + 256 * i;
-      const int row = q >> 5, cc = q & 31;
-      const int idx = blockIdx.x * PANEL_ROWS + (row - NB);
-      if (idx < rows_below)
-        *reinterpret_cast<d2*>(A + (int64_t)(NB + idx) * lda + 2 * cc) = d2{sOut[row * POUT + 2 * cc], sOut[row * POUT + 2 * cc + 1]};
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // the factored diagonal block (zeros right of the diagonal) -> staging
-      const int q = c.tid + 256 * i;
-      const int row = q >> 5, cc = q & 31;
-      *reinterpret_cast<d2*>(stage_out + row * NB + 2 * cc) = d2{sOut[row * POUT + 2 * cc], sOut[row * POUT + 2 * cc + 1]};
-    }
-    // identity row i came out as column i of L11^-1
-    for (int e = c.tid; e < NB * NB; e += 256) {
-      const int kk = e >> 6, i = e & 63;
-      inv_diag[e] = sOut[(NB + i) * POUT + kk];
-    }
-    if (c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
-  }
+  if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
   PSTAMP(5)
 }
 
