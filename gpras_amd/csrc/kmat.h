@@ -76,6 +76,7 @@ struct KmatArgs {
   double variance, diag_add;
   int mode;              // 0: rectangle (zero padding), 1: symmetric, tiles on/below the diagonal only, 2: symmetric, all tiles
   double pad_diag;       // value written on the diagonal of the padding (1 for symmetric modes, else 0)
+  const double* dparams; // optional device-resident {variance, diag_add} overriding the two fields above (graph replay)
   int tiles_n;
 };
 
@@ -133,6 +134,10 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
     __syncthreads();
   }
 
+  if (p.dparams) {
+    p.variance = p.dparams[0];
+    p.diag_add = p.dparams[1];
+  }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int i = i0 + wave * 16 + 2 * it + rsub;

