@@ -66,6 +66,10 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # RCCL and the HIP runtime print banners to stdout: keep stdout for the one JSON line only
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -306,11 +310,13 @@ def main():
 
     for c in range(cells):
         lib.gprx_destroy(C.c_void_p(handles[c]))
-    if rank == 0:
-        print(json.dumps(result))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
