@@ -192,7 +192,7 @@ def main():
         gemm_ms, gemm_launches, gemm_flops, panel_ms, panel_launches, strip_ms, strip_launches, strip_flops = acc / reps
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "gprx::gemm_f64_kernel<0,1,64,64> (Cholesky bulk trailing update A22 -= L21 L21^T, K = 256: HEAD + TAIL launches)",
+            "kernel": "gprx::gemm_f64_kernel<0,1,64,64> (Cholesky bulk trailing update A22 -= L21 L21^T, K = 1024: HEAD + TAIL launches)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -14,6 +14,7 @@
 //      diagonal block, used by the triangular solves).
 //   2. gemm_f64 (NT, C_LOWER, alpha = -1, beta = 1) -- trailing update A22 -= L21 L21^T on MFMA.
 #pragma once
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -491,7 +492,12 @@ struct PotrfTuning {
   int no_lookahead = 0;  // 1: everything on the main stream (debugging)
 };
 inline PotrfTuning& potrf_tuning() {
-  static PotrfTuning t;
+  static PotrfTuning t = [] {
+    PotrfTuning v;
+    if (const char* e = getenv("GPRX_OUTER_BLOCK")) v.outer_block = atoi(e);  // experiments without recompiling callers
+    if (const char* e = getenv("GPRX_UPDATE_TILE")) v.update_tile = atoi(e);
+    return v;
+  }();
   return t;
 }
 
@@ -520,8 +526,9 @@ struct PotrfStreams {
 // Two-level right-looking schedule with look-ahead.  Panels are 64 columns wide by default (one launch
 // factors the diagonal block and solves all rows below it; the 128-column kernel is selectable with
 // gprx_set_tuning and measured slower: its MFMA updates serialise behind the scalar factor chain).
-// Outer blocks are `ob` columns (256 below n = 8192, else 512, measured): the bulk trailing updates
-// run with K = ob, i.e. n / ob passes over the trailing matrix instead of n / 64.  For each outer block J =
+// Outer blocks are `ob` columns (1024 up to n = 4096, else 512, measured): the bulk trailing updates
+// run with K = ob, i.e. n / ob passes over the trailing matrix instead of n / 64; inside a block the
+// K = 64 strip kernel updates the block's remaining columns after every panel.  For each outer block J =
 // columns [C, C + w):
 //   main stream: its panels, each followed by the strip update of the block's remaining columns;
 //                then HEAD(J): the update of the NEXT block's columns by block J (K = w);
@@ -548,7 +555,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   const int total_rows = np + extra;
   const PotrfTuning& tune = potrf_tuning();
   if (tune.no_lookahead) ps = nullptr;
-  const int ob = tune.outer_block ? tune.outer_block : (np >= 8192 ? 512 : 256);
+  const int ob = tune.outer_block ? tune.outer_block : (np > 4096 ? 512 : 1024);  // measured: N=2048/4096 -> 1024, N=8192/16384 -> 512
   const int pwidth = tune.panel_width ? tune.panel_width : NB;
   bool tail_pending = false;
   for (int C = 0; C < np; C += ob) {
