@@ -101,8 +101,10 @@ __device__ __forceinline__ void store_mc(double* s, const d2 (&r)[COLS / 32], in
 // ---- the kernel ----------------------------------------------------------------------------
 // TA == 0: A stored M x K (KC image);  TA == 1: A stored K x M (MC image), op(A) = A^T.
 // TB == 1: B stored N x K (KC image), op(B) = B^T;  TB == 0: B stored K x N (MC image).
-template <int TA, int TB, int BM, int BN>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_kernel(GemmArgs p) {
+// PF: fetch C before the main loop (beta != 0, short K: hides the C latency; costs 32 VGPRs on the 64 x 64 tile,
+// i.e. one workgroup of occupancy, so long-K launches use PF = 0)
+template <int TA, int TB, int BM, int BN, int PF = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (PF ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
   constexpr int B_ELEMS = TB ? BN * GEMM_LDK : GEMM_BK * McStride<BN>::value;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 3) void gemm_f64_
     for (int b = 0; b < TN; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
   // beta != 0 on a small tile: fetch C before the main loop so that its latency hides under the MFMAs
-  constexpr bool kPrefetchC = (BM * BN <= 64 * 64);
+  constexpr bool kPrefetchC = PF != 0;
   double cpre[kPrefetchC ? TM : 1][kPrefetchC ? TN : 1][4];
   if constexpr (kPrefetchC) {
     if (p.beta != 0.0) {
@@ -308,7 +310,11 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
   } else {
     p.nwg = p.tiles_m * p.tiles_n;
   }
-  hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+  if (BM * BN <= 64 * 64 && p.beta != 0.0 && p.K <= 128 && nsplit == 1) {
+    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, 0>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+  }
   return hipGetLastError();
 }
 

@@ -980,6 +980,7 @@ int gprx_set_tuning(const char* key, int value) {
   else if (k == "outer_block" && value >= 0 && value % 128 == 0) t.outer_block = value;
   else if (k == "update_tile" && (value == 0 || value == 64 || value == 128)) t.update_tile = value;
   else if (k == "no_lookahead") t.no_lookahead = value != 0;
+  else if (k == "panel_rows" && (value == 0 || value == 128 || value == 256)) t.panel_rows = value;
   else return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
   return GPRX_OK;
 }

@@ -19,19 +19,19 @@ constexpr int KM_DC = 8;   // coordinates staged per LDS pass
 template <int KID>
 __device__ __forceinline__ double corr_g(double r2) {
   if constexpr (KID == 0) {
-    return exp(-0.5 * r2);
+    return exp_nonpos(-0.5 * r2);
   } else {
     const double r = sqrt(fmax(r2, R2_FLOOR));
-    if constexpr (KID == 1) return exp(-r);
+    if constexpr (KID == 1) return exp_nonpos(-r);
     if constexpr (KID == 2) {
       const double t = 1.7320508075688772 * r;
-      return (1.0 + t) * exp(-t);
+      return (1.0 + t) * exp_nonpos(-t);
     }
     if constexpr (KID == 3) {
       const double t = 2.23606797749979 * r;
-      return (1.0 + t + (5.0 / 3.0) * r * r) * exp(-t);
+      return (1.0 + t + (5.0 / 3.0) * r * r) * exp_nonpos(-t);
     }
-    return exp(-0.5 * r);
+    return exp_nonpos(-0.5 * r);
   }
 }
 
@@ -39,26 +39,26 @@ __device__ __forceinline__ double corr_g(double r2) {
 template <int KID>
 __device__ __forceinline__ void corr_gh(double r2, double& g, double& h) {
   if constexpr (KID == 0) {
-    g = exp(-0.5 * r2);
+    g = exp_nonpos(-0.5 * r2);
     h = -g;
   } else {
     const bool live = r2 >= R2_FLOOR;
     const double r = sqrt(fmax(r2, R2_FLOOR));
     if constexpr (KID == 1) {
-      g = exp(-r);
+      g = exp_nonpos(-r);
       h = -g / r;
     } else if constexpr (KID == 2) {
       const double t = 1.7320508075688772 * r;
-      const double e = exp(-t);
+      const double e = exp_nonpos(-t);
       g = (1.0 + t) * e;
       h = -3.0 * e;
     } else if constexpr (KID == 3) {
       const double t = 2.23606797749979 * r;
-      const double e = exp(-t);
+      const double e = exp_nonpos(-t);
       g = (1.0 + t + (5.0 / 3.0) * r * r) * e;
       h = -(5.0 / 3.0) * (1.0 + t) * e;
     } else {
-      g = exp(-0.5 * r);
+      g = exp_nonpos(-0.5 * r);
       h = -0.5 * g / r;
     }
     if (!live) h = 0.0;

@@ -30,14 +30,19 @@ __device__ unsigned long long g_panel_stamps[64];
 #define PSTAMP(i)
 #endif
 
-constexpr int PANEL_ROWS = 64;   // rows of A21 per workgroup (workgroup rows 64..127; rows 0..63 = the diagonal block)
-constexpr int PWG_ROWS = 128;    // rows held by one workgroup
+// RT = 16-row tiles per wave: 2 -> 128 rows per workgroup (64 of A21), 4 -> 256 rows per workgroup (192 of A21).
+// Fewer, fatter workgroups leave CUs to other cells' GEMMs when several cells are in flight.
+template <int RT>
+struct PanelGeom {
+  static constexpr int kWgRows = 64 * RT;      // rows held by one workgroup (rows 0..63 = the diagonal block)
+  static constexpr int kOwnRows = 64 * RT - NB;  // rows of A21 per workgroup
+};
 constexpr int PSUB = 9;          // LDS row stride of the 8-column sub-panel buffers (row-per-lane b64 access conflict-free)
 
 // State shared by the unrolled sub-panel steps.
 struct PanelCtx {
-  double* sIn;    // [128][9]  current sub-panel, as updated so far (written from the accumulators)
-  double* sX;     // [128][9]  current sub-panel, solved (MFMA operands of the trailing update)
+  double* sIn;    // [rows][9]  current sub-panel, as updated so far (written from the accumulators)
+  double* sX;     // [rows][9]  current sub-panel, solved (MFMA operands of the trailing update)
   double* out;    // this thread's output row (global memory or the diagonal-block staging area); nullptr: none
   double* inv_diag;
   int ident;      // >= 0: this thread carries identity row `ident` (last workgroup)
@@ -46,10 +51,12 @@ struct PanelCtx {
   int bad;
 };
 
-// One 8-column sub-panel.  acc[rt][kt]: this wave's 32 rows x 64 columns in MFMA C/D layout
-// (lane (g, r) holds rows 32 w + 16 rt + g + 4 q, column 16 kt + r).
-template <int P>
-__device__ __forceinline__ void panel_step(d4 (&acc)[2][4], PanelCtx& c) {
+// One 8-column sub-panel.  acc[rt][kt]: this wave's 16 RT rows x 64 columns in MFMA C/D layout
+// (lane (g, r) holds rows 16 RT w + 16 rt + g + 4 q, column 16 kt + r).
+template <int P, int RT>
+__device__ __forceinline__ void panel_step(d4 (&acc)[RT][4], PanelCtx& c) {
+  constexpr int WROWS = 16 * RT;                 // rows per wave
+  constexpr int PWG_ROWS = PanelGeom<RT>::kWgRows;
   constexpr int C0 = 8 * P;
   constexpr int KT = C0 / 16;      // tile column holding this sub-panel
   constexpr int HALF = P & 1;      // which 8 columns of that tile
@@ -57,9 +64,9 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[2][4], PanelCtx& c) {
   // A: accumulators -> LDS (only the lanes that hold these 8 columns)
   if ((c.r >> 3) == HALF) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c.sIn[(32 * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)] = acc[rt][KT][q];
+      for (int q = 0; q < 4; ++q) c.sIn[(WROWS * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)] = acc[rt][KT][q];
   }
   __syncthreads();
   if constexpr (P == 1) { PSTAMP(11) }
@@ -119,11 +126,11 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[2][4], PanelCtx& c) {
   // C: trailing columns [C0 + 8, 64) of this wave's rows: acc -= X_rows (32 x 8) * X_diag(16 kt .. +15, 8)^T
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
-    double fa[2][2], fb[4][2];
+    double fa[RT][2], fb[4][2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -c.sX[(32 * c.wave + 16 * rt + c.r) * PSUB + 4 * ks + c.g];
+      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -c.sX[(WROWS * c.wave + 16 * rt + c.r) * PSUB + 4 * ks + c.g];
 #pragma unroll
     for (int kt = KT0; kt < 4; ++kt) {
       const int kk = kt * 16 + c.r;
@@ -135,7 +142,7 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[2][4], PanelCtx& c) {
 #pragma unroll
     for (int kt = KT0; kt < 4; ++kt)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
       }
@@ -166,10 +173,14 @@ __global__ __launch_bounds__(256) void copy_block_kernel(const double* __restric
   flush_staged_block(stage, dst, lda, pw, threadIdx.x);
 }
 
+template <int RT>
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
                                                           double* __restrict__ inv_diag, int* __restrict__ info, int col0,
                                                           double* __restrict__ stage_out, const double* __restrict__ prev_stage,
                                                           double* __restrict__ prev_dst, int prev_pw) {
+  constexpr int PWG_ROWS = PanelGeom<RT>::kWgRows;
+  constexpr int PANEL_ROWS = PanelGeom<RT>::kOwnRows;
+  constexpr int WROWS = 16 * RT;
   __shared__ __attribute__((aligned(16))) double sIn[PWG_ROWS * PSUB];
   __shared__ __attribute__((aligned(16))) double sX[PWG_ROWS * PSUB];
   PanelCtx c;
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   c.bad = 0;
   const bool last = (int)blockIdx.x == nchunks;
   if (last) flush_staged_block(prev_stage, prev_dst, lda, prev_pw, c.tid);
-  // where this thread's solved row goes (threads 0..127 own workgroup rows 0..127)
+  // where this thread's solved row goes (thread t < PWG_ROWS owns workgroup row t)
   c.out = nullptr;
   c.ident = -1;
   if (c.tid < NB) {
@@ -194,19 +205,19 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     if (!last) {
       const int idx = blockIdx.x * PANEL_ROWS + (c.tid - NB);
       if (idx < rows_below) c.out = A + (int64_t)(NB + idx) * lda;
-    } else {
+    } else if (c.tid < 2 * NB) {
       c.ident = c.tid - NB;
     }
   }
   PSTAMP(0)
 
   // ---- load straight into the accumulator layout (32 loads per lane, all in flight) ----
-  d4 acc[2][4];
+  d4 acc[RT][4];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int wrow = 32 * c.wave + 16 * rt + c.g + 4 * q;  // workgroup row 0..127
+      const int wrow = WROWS * c.wave + 16 * rt + c.g + 4 * q;  // workgroup row
       const double* src = nullptr;
       if (wrow < NB) {
         src = A + (int64_t)wrow * lda;
@@ -229,16 +240,16 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     }
   PSTAMP(1)
 
-  panel_step<0>(acc, c);
+  panel_step<0, RT>(acc, c);
   PSTAMP(2)
-  panel_step<1>(acc, c);
-  panel_step<2>(acc, c);
-  panel_step<3>(acc, c);
+  panel_step<1, RT>(acc, c);
+  panel_step<2, RT>(acc, c);
+  panel_step<3, RT>(acc, c);
   PSTAMP(3)
-  panel_step<4>(acc, c);
-  panel_step<5>(acc, c);
-  panel_step<6>(acc, c);
-  panel_step<7>(acc, c);
+  panel_step<4, RT>(acc, c);
+  panel_step<5, RT>(acc, c);
+  panel_step<6, RT>(acc, c);
+  panel_step<7, RT>(acc, c);
   PSTAMP(4)
   if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
   PSTAMP(5)
@@ -490,12 +501,14 @@ struct PotrfTuning {
   int outer_block = 0;   // multiple of 128
   int update_tile = 0;   // tile of the TAIL GEMM: 64 or 128
   int no_lookahead = 0;  // 1: everything on the main stream (debugging)
+  int panel_rows = 0;    // rows per panel workgroup: 128 (default) or 256
 };
 inline PotrfTuning& potrf_tuning() {
   static PotrfTuning t = [] {
     PotrfTuning v;
     if (const char* e = getenv("GPRX_OUTER_BLOCK")) v.outer_block = atoi(e);  // experiments without recompiling callers
     if (const char* e = getenv("GPRX_UPDATE_TILE")) v.update_tile = atoi(e);
+    if (const char* e = getenv("GPRX_PANEL_ROWS")) v.panel_rows = atoi(e);
     return v;
   }();
   return t;
@@ -575,9 +588,17 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
         hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
                            inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
       } else {
-        const int nchunks = (rows_below + PANEL_ROWS - 1) / PANEL_ROWS;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                           inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+        if (tune.panel_rows == 256) {
+          const int own = PanelGeom<4>::kOwnRows;
+          const int nchunks = (rows_below + own - 1) / own;
+          hipLaunchKernelGGL(potrf_panel_kernel<4>, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+        } else {
+          const int own = PanelGeom<2>::kOwnRows;
+          const int nchunks = (rows_below + own - 1) / own;
+          hipLaunchKernelGGL(potrf_panel_kernel<2>, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+        }
       }
       prev_stage = stage_out;
       prev_dst = Acc;
