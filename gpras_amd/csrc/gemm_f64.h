@@ -325,9 +325,12 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
 constexpr int S64_LD = 64 + 2;  // LDS row stride (doubles)
 
 __global__ __launch_bounds__(256) void syrk_k64_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
-                                                       int64_t lda, int64_t ldc, int M, int N, int tiles_n) {
+                                                       int64_t lda, int64_t ldc, int M, int N, int tiles_n, int64_t cs) {
   __shared__ __attribute__((aligned(16))) double sA[64 * S64_LD];
   __shared__ __attribute__((aligned(16))) double sB[64 * S64_LD];
+  A += (int64_t)blockIdx.y * cs;  // batched: blockIdx.y = cell, cs = cell stride (0 for a single matrix)
+  B += (int64_t)blockIdx.y * cs;
+  C += (int64_t)blockIdx.y * cs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
   // lower-trapezoid tile decode (tiles are square: tile (ti, tj) has work iff tj <= ti)
@@ -409,13 +412,14 @@ __global__ __launch_bounds__(256) void syrk_k64_kernel(const double* __restrict_
 }
 
 // C(M x N) -= A(M x 64) A(first N rows)^T, lower trapezoid only (M >= N)
-inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A, int64_t lda, double* C, int64_t ldc) {
+inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A, int64_t lda, double* C, int64_t ldc, int batch = 1,
+                                  int64_t cs = 0) {
   const int tm = (M + 63) / 64;
   int tn = (N + 63) / 64;
   if (tm == 0 || tn == 0) return hipSuccess;
   if (tn > tm) tn = tm;
   const int nwg = tn * (tn + 1) / 2 + (tm - tn) * tn;
-  hipLaunchKernelGGL(syrk_k64_kernel, dim3(nwg), dim3(256), 0, st, A, A, C, lda, ldc, M, N, tn);
+  hipLaunchKernelGGL(syrk_k64_kernel, dim3(nwg, batch), dim3(256), 0, st, A, A, C, lda, ldc, M, N, tn, cs);
   return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,9 +31,17 @@ thread_local std::string g_err;
 struct Buf {
   double* p = nullptr;
   size_t bytes = 0;
+  bool borrowed = false;  // view into the batch arena (gprx_select_slot): never freed through this Buf
 };
 
 }  // namespace
+
+struct Theta {
+  double variance, noise;
+  std::vector<double> ls;
+  double w_var, w_noise;
+  std::vector<double> w_len;
+};
 
 struct gprx_ctx {
   int device = 0;
@@ -64,6 +73,17 @@ struct gprx_ctx {
   PotrfStreams pstreams;
   double prof_out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // batched exact factorisations (gprx_factorize_batch): `arena_slots` cell blocks, `cell_stride` doubles apart, each
+  // [K (np + 64) x np | invD np x 64 | staged diagonal blocks np x 128 | alpha np]; parameter / result tables, one row per cell
+  Buf arena, cellpar, cellres;
+  double* bpin = nullptr;  // pinned: [slots][CELL_PAR] parameters up, then [slots][CELL_RES] results down
+  int arena_slots = 0;
+  int64_t cell_stride = 0, off_invd = 0, off_stage = 0, off_alpha = 0;
+  std::vector<Theta> slot_theta;
+  std::vector<int> slot_unit;
+  std::vector<char> slot_ok;
+  double batch_ms = 0.0;  // device time of the last batch (events around the whole batch)
+  hipEvent_t bev[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -85,9 +105,10 @@ int fail(gprx_handle h, int code, const std::string& msg) {
 
 int ensure(gprx_handle h, Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return GPRX_OK;
-  if (b.p) HIPCHK(h, hipFree(b.p));
+  if (b.p && !b.borrowed) HIPCHK(h, hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
+  b.borrowed = false;
   HIPCHK(h, hipMalloc((void**)&b.p, bytes));
   b.bytes = bytes;
   return GPRX_OK;
@@ -136,13 +157,6 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
   const d4 s = c0 + c1 + c2 + c3;
   if (s.x == 123.456) out[0] = s.y;
 }
-
-struct Theta {
-  double variance, noise;
-  std::vector<double> ls;
-  double w_var, w_noise;
-  std::vector<double> w_len;
-};
 
 Theta decode_theta(gprx_handle h, const double* theta) {
   Theta t;
@@ -218,7 +232,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
   hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
-  hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, h->Kmat.p, ld, beta, np, h->red.p);
+  hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, (const double*)h->Kmat.p, ld, beta, np, h->red.p, (int64_t)0, 0);
   HIPCHK(h, trsv_lower(st, h->Kmat.p, ld, h->invD.p, h->alpha.p, np, true));
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[3], st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 64, h->red.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
@@ -322,6 +336,182 @@ int exact_factorize(gprx_handle h, int unit, const Theta& t, double* lml_out) {
   int rc = exact_factorize_enqueue(h, unit, t);
   if (rc) return rc;
   return exact_factorize_finish(h, lml_out);
+}
+
+// ---- batched exact factorisations -------------------------------------------------------------------------
+// Independent cells (one unit and one hyperparameter vector each, all on this handle's x) factorised by the
+// SAME launches: every kernel of the single-cell schedule carries the cell index in a grid dimension, so one
+// panel launch is cells x (rows / 128) workgroups and one trailing update is cells x tiles -- the chip is full
+// although a single N = 4096 panel occupies 33 of 256 CUs.  Same kernels, same per-element operation order:
+// the results are bit-identical to gprx_factorize on each cell.
+constexpr int CELL_RES = 4;  // per cell: [0] sum log diag L, [1] |L^-1 y|^2, [2] info (int), [3] unused
+
+__global__ void set_rhs_rows_batch_kernel(double* dst, int64_t ld, const double* ybase, const double* cell_par, int n, int np, int rows,
+                                          int64_t cs) {
+  const int cell = blockIdx.y;
+  const double* y = ybase + (int64_t)cell_par[(int64_t)cell * CELL_PAR + 2] * np;
+  dst += (int64_t)cell * cs;
+  const int64_t total = (int64_t)rows * np;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / np), c = (int)(e % np);
+    dst[(int64_t)r * ld + c] = (r == 0 && c < n) ? y[c] : 0.0;
+  }
+}
+
+__global__ void copy_row_batch_kernel(const double* src, double* dst, int n, int64_t cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(int64_t)blockIdx.y * cs + i] = src[(int64_t)blockIdx.y * cs + i];
+}
+
+void drop_graphs(gprx_handle h) {
+  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  h->graphs.clear();
+}
+
+// views of the single-cell buffers into the arena are invalid once it moves
+void drop_arena_views(gprx_handle h) {
+  for (Buf* b : {&h->Kmat, &h->invD, &h->alpha})
+    if (b->borrowed) {
+      b->p = nullptr;
+      b->bytes = 0;
+      b->borrowed = false;
+      h->factorized = false;
+      h->have_linv = false;
+    }
+  drop_graphs(h);
+}
+
+int ensure_arena(gprx_handle h, int slots) {
+  if (h->arena_slots >= slots) return GPRX_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  drop_arena_views(h);
+  const int64_t np = h->np;
+  h->off_invd = (np + NB) * np;
+  h->off_stage = h->off_invd + np * NB;
+  h->off_alpha = h->off_stage + np * PW;
+  h->cell_stride = round_up(h->off_alpha + np, 64);
+  for (Buf* b : {&h->arena, &h->cellpar, &h->cellres}) {
+    if (b->p) HIPCHK(h, hipFree(b->p));
+    b->p = nullptr;
+    b->bytes = 0;
+  }
+  if (h->bpin) HIPCHK(h, hipHostFree(h->bpin));
+  h->bpin = nullptr;
+  h->arena_slots = 0;
+  int rc;
+  if ((rc = ensure(h, h->arena, sizeof(double) * (size_t)h->cell_stride * slots))) return rc;
+  if ((rc = ensure(h, h->cellpar, sizeof(double) * CELL_PAR * slots))) return rc;
+  if ((rc = ensure(h, h->cellres, sizeof(double) * CELL_RES * slots))) return rc;
+  HIPCHK(h, hipHostMalloc((void**)&h->bpin, sizeof(double) * (CELL_PAR + CELL_RES) * slots, hipHostMallocDefault));
+  if (!h->bev[0]) {
+    HIPCHK(h, hipEventCreate(&h->bev[0]));
+    HIPCHK(h, hipEventCreate(&h->bev[1]));
+  }
+  h->arena_slots = slots;
+  h->slot_theta.assign(slots, Theta());
+  h->slot_unit.assign(slots, -1);
+  h->slot_ok.assign(slots, 0);
+  return GPRX_OK;
+}
+
+int exact_factorize_batch(gprx_handle h, int count, const int* units, const Theta* ts, double* lml_out, int* status_out) {
+  int rc;
+  if ((rc = ensure_arena(h, count))) return rc;
+  const int np = (int)h->np;
+  const int64_t ld = h->np, cs = h->cell_stride;
+  hipStream_t st = h->stream;
+  double* par = h->bpin;
+  double* res = h->bpin + (size_t)CELL_PAR * h->arena_slots;
+  for (int c = 0; c < count; ++c) {
+    double* row = par + (size_t)c * CELL_PAR;
+    std::memset(row, 0, sizeof(double) * CELL_PAR);
+    row[0] = ts[c].variance;
+    row[1] = ts[c].noise;
+    row[2] = (double)units[c];
+    for (int k = 0; k < h->d; ++k) row[CELL_PAR_LS + k] = ts[c].ls[k];
+    h->slot_ok[c] = 0;
+  }
+  const bool lookahead = !potrf_tuning().no_lookahead && getenv("GPRX_BATCH_LOOKAHEAD") != nullptr;
+  if (lookahead && (rc = ensure_lookahead(h))) return rc;
+  HIPCHK(h, hipEventRecord(h->bev[0], st));
+  HIPCHK(h, hipMemcpyAsync(h->cellpar.p, par, sizeof(double) * CELL_PAR * count, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(h->cellres.p, 0, sizeof(double) * CELL_RES * count, st));
+  double* K0 = h->arena.p;
+  KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
+  ka.cell_par = h->cellpar.p;
+  ka.out_stride = cs;
+  HIPCHK(h, launch_kmat(st, h->kid, ka, count));
+  hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, count), dim3(256), 0, st, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p,
+                     (const double*)h->cellpar.p, (int)h->n, np, NB, cs);
+  int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
+  HIPCHK(h, potrf_lower(st, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, nullptr, lookahead ? &h->pstreams : nullptr, count, cs,
+                        2 * CELL_RES));
+  const double* beta = K0 + (int64_t)np * ld;
+  hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, count), dim3(256), 0, st, beta, K0 + h->off_alpha, np, cs);
+  hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)K0, ld, beta, np, h->cellres.p, cs, CELL_RES);
+  HIPCHK(h, trsv_lower(st, K0, ld, K0 + h->off_invd, K0 + h->off_alpha, np, true, count, cs));
+  HIPCHK(h, hipMemcpyAsync(res, h->cellres.p, sizeof(double) * CELL_RES * count, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipEventRecord(h->bev[1], st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->bev[0], h->bev[1]);
+  h->batch_ms = ms;
+  int first_error = GPRX_OK;
+  for (int c = 0; c < count; ++c) {
+    int info = 0;
+    std::memcpy(&info, res + (size_t)c * CELL_RES + 2, sizeof(int));
+    h->slot_theta[c] = ts[c];
+    h->slot_unit[c] = units[c];
+    h->slot_ok[c] = info == 0;
+    if (status_out) status_out[c] = info == 0 ? GPRX_OK : GPRX_ENOTPD;
+    if (info != 0) {
+      if (!first_error) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "cell %d: matrix not positive definite: pivot %d", c, info);
+        first_error = fail(h, GPRX_ENOTPD, msg);
+      }
+      if (lml_out) lml_out[c] = std::numeric_limits<double>::quiet_NaN();
+      continue;
+    }
+    const double* r = res + (size_t)c * CELL_RES;
+    if (lml_out) lml_out[c] = -0.5 * r[1] - r[0] - 0.5 * (double)h->n * std::log(2.0 * M_PI);
+  }
+  // a single-cell view into a slot of this batch is stale now
+  for (Buf* b : {&h->Kmat, &h->invD, &h->alpha})
+    if (b->borrowed) {
+      h->factorized = false;
+      h->have_linv = false;
+    }
+  return first_error;
+}
+
+// make slot `slot` of the last batch the handle's current factorisation (predict / gradient work on it)
+int select_slot(gprx_handle h, int slot) {
+  if (slot < 0 || slot >= h->arena_slots || h->slot_unit[slot] < 0) return fail(h, GPRX_EINVAL, "slot holds no factorisation");
+  if (!h->slot_ok[slot]) return fail(h, GPRX_ESTATE, "the factorisation of this slot failed");
+  double* base = h->arena.p + (int64_t)slot * h->cell_stride;
+  auto view = [&](Buf& b, double* p, size_t bytes) {
+    if (b.p && !b.borrowed) hipFree(b.p);
+    b.p = p;
+    b.bytes = bytes;
+    b.borrowed = true;
+  };
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->Kmat.p != base) drop_graphs(h);
+  view(h->Kmat, base, sizeof(double) * (h->np + NB) * h->np);
+  view(h->invD, base + h->off_invd, sizeof(double) * h->np * NB);
+  view(h->alpha, base + h->off_alpha, sizeof(double) * h->np);
+  const Theta& t = h->slot_theta[slot];
+  int rc;
+  if ((rc = upload_inv_ls(h, t))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->cur_unit = h->slot_unit[slot];
+  h->variance = t.variance;
+  h->noise = t.noise;
+  h->ls = t.ls;
+  h->factorized = true;
+  h->have_linv = false;
+  return GPRX_OK;
 }
 
 // gradient of the LML w.r.t. constrained (variance, lengthscales[nlen], noise) -> g[0 .. nlen+1]
@@ -431,7 +621,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   }
   HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info, h->dstage.p, nullptr, nullptr));
   HIPCHK(h, hipEventRecord(h->ev[2], st));
-  hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, crow, mp, h->red.p);
+  hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, (const double*)h->Bm.p, (int64_t)mp, (const double*)crow, mp, h->red.p, (int64_t)0, 0);
   HIPCHK(h, hipEventRecord(h->ev[3], st));
   double red[3];
   int info = 0;
@@ -611,8 +801,11 @@ int gprx_destroy(gprx_handle h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
                  &h->pred, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs, &h->dZ,
-                 &h->dstage, &h->splitws})
-    if (b->p) hipFree(b->p);
+                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres})
+    if (b->p && !b->borrowed) hipFree(b->p);
+  if (h->bpin) hipHostFree(h->bpin);
+  for (auto& ev : h->bev)
+    if (ev) hipEventDestroy(ev);
   if (h->info) hipFree(h->info);
   if (h->pin) hipHostFree(h->pin);
   if (h->gparams) hipFree(h->gparams);
@@ -755,6 +948,39 @@ int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const
     if (!rc && losses) losses[i] = -(lml + log_prior(h, ts[i], mask));
   }
   return first_error;
+}
+
+int gprx_factorize_batch(gprx_handle h, int count, const int* units, const double* thetas, int mask, double* losses, int* status) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (count <= 0 || !units || !thetas) return fail(h, GPRX_EINVAL, "count must be positive, units and thetas non-null");
+  if (h->m != 0) return fail(h, GPRX_EINVAL, "gprx_factorize_batch: exact models only");
+  if (h->d > CELL_PAR - CELL_PAR_LS) return fail(h, GPRX_EINVAL, "gprx_factorize_batch: d <= 64 only");
+  std::vector<Theta> ts(count);
+  for (int i = 0; i < count; ++i) {
+    if (units[i] < 0 || units[i] >= h->n_units) return fail(h, GPRX_EINVAL, "unit out of range (call gprx_set_data first)");
+    for (int k = 0; k < h->ntheta; ++k)
+      if (!std::isfinite(thetas[(int64_t)i * h->ntheta + k])) return fail(h, GPRX_EINVAL, "theta is not finite");
+    ts[i] = decode_theta(h, thetas + (int64_t)i * h->ntheta);
+  }
+  std::vector<double> lml(count);
+  rc = exact_factorize_batch(h, count, units, ts.data(), lml.data(), status);
+  if (rc != GPRX_OK && rc != GPRX_ENOTPD) return rc;
+  if (losses)
+    for (int i = 0; i < count; ++i) losses[i] = -(lml[i] + log_prior(h, ts[i], mask));  // NaN for a failed cell
+  return rc;
+}
+
+int gprx_select_slot(gprx_handle h, int slot) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  return select_slot(h, slot);
+}
+
+int gprx_last_batch_ms(gprx_handle h, double* ms) {
+  if (!h || !ms) return fail(h, GPRX_EINVAL, "null argument");
+  *ms = h->batch_ms;
+  return GPRX_OK;
 }
 
 int gprx_last_timings(gprx_handle h, double* ms4) {

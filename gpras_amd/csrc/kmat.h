@@ -78,7 +78,13 @@ struct KmatArgs {
   double pad_diag;       // value written on the diagonal of the padding (1 for symmetric modes, else 0)
   const double* dparams; // optional device-resident {variance, diag_add} overriding the two fields above (graph replay)
   int tiles_n;
+  // batched build (blockIdx.y = cell): cell c writes out + c * out_stride with the parameters of row c of the
+  // cell-parameter table, CELL_PAR doubles per row: [0] variance, [1] diag_add, [2] unit, [8 .. 8 + d) lengthscales
+  const double* cell_par = nullptr;
+  int64_t out_stride = 0;
 };
+constexpr int CELL_PAR = 72;
+constexpr int CELL_PAR_LS = 8;
 
 // Stage KM_DC scaled coordinates of 64 points: sA[point][KM_DC] (row broadcast reads),
 // sBt[KM_DC][64] (lane-contiguous reads).
@@ -91,6 +97,12 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   const int i0 = ti * KM_T, j0 = tj * KM_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cp = lane & 31, rsub = lane >> 5;
+  if (p.cell_par) {
+    const double* par = p.cell_par + (int64_t)blockIdx.y * CELL_PAR;
+    p.ls = par + CELL_PAR_LS;
+    p.dparams = par;
+    p.out += (int64_t)blockIdx.y * p.out_stride;
+  }
 
   double acc[8][2];
 #pragma unroll
@@ -153,11 +165,11 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   }
 }
 
-inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p) {
+inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p, int batch = 1) {
   const int tiles_m = (p.n1p + KM_T - 1) / KM_T;
   p.tiles_n = (p.n2p + KM_T - 1) / KM_T;
   if (tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
-  dim3 grid(tiles_m * p.tiles_n), block(256);
+  dim3 grid(tiles_m * p.tiles_n, batch), block(256);
   switch (kid) {
     case 0: hipLaunchKernelGGL(kmat_kernel<0>, grid, block, 0, st, p); break;
     case 1: hipLaunchKernelGGL(kmat_kernel<1>, grid, block, 0, st, p); break;

@@ -169,18 +169,29 @@ __device__ __forceinline__ void flush_staged_block(const double* __restrict__ pr
   }
 }
 
-__global__ __launch_bounds__(256) void copy_block_kernel(const double* __restrict__ stage, double* __restrict__ dst, int64_t lda, int pw) {
-  flush_staged_block(stage, dst, lda, pw, threadIdx.x);
+__global__ __launch_bounds__(256) void copy_block_kernel(const double* __restrict__ stage, double* __restrict__ dst, int64_t lda, int pw,
+                                                         int64_t cs) {
+  flush_staged_block(stage + (int64_t)blockIdx.x * cs, dst + (int64_t)blockIdx.x * cs, lda, pw, threadIdx.x);
 }
 
 template <int RT>
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
                                                           double* __restrict__ inv_diag, int* __restrict__ info, int col0,
                                                           double* __restrict__ stage_out, const double* __restrict__ prev_stage,
-                                                          double* __restrict__ prev_dst, int prev_pw) {
+                                                          double* __restrict__ prev_dst, int prev_pw, int64_t cs, int info_stride) {
   constexpr int PWG_ROWS = PanelGeom<RT>::kWgRows;
   constexpr int PANEL_ROWS = PanelGeom<RT>::kOwnRows;
   constexpr int WROWS = 16 * RT;
+  {
+    // batched: blockIdx.y = cell; every per-cell pointer lives in one cell block, `cs` doubles apart
+    const int64_t off = (int64_t)blockIdx.y * cs;
+    A += off;
+    inv_diag += off;
+    stage_out += off;
+    if (prev_stage) prev_stage += off;
+    if (prev_dst) prev_dst += off;
+    info += (int64_t)blockIdx.y * info_stride;
+  }
   __shared__ __attribute__((aligned(16))) double sIn[PWG_ROWS * PSUB];
   __shared__ __attribute__((aligned(16))) double sX[PWG_ROWS * PSUB];
   PanelCtx c;
@@ -394,7 +405,16 @@ constexpr int PANEL128_ROWS = 128;  // rows of A21 per workgroup
 __global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
                                                              double* __restrict__ inv_diag, int* __restrict__ info, int col0,
                                                              double* __restrict__ stage_out, const double* __restrict__ prev_stage,
-                                                             double* __restrict__ prev_dst, int prev_pw) {
+                                                             double* __restrict__ prev_dst, int prev_pw, int64_t cs, int info_stride) {
+  {
+    const int64_t off = (int64_t)blockIdx.y * cs;
+    A += off;
+    inv_diag += off;
+    stage_out += off;
+    if (prev_stage) prev_stage += off;
+    if (prev_dst) prev_dst += off;
+    info += (int64_t)blockIdx.y * info_stride;
+  }
   __shared__ __attribute__((aligned(16))) double sIn[256 * PSUB];
   __shared__ __attribute__((aligned(16))) double sX[256 * PSUB];
   Panel128Ctx c;
@@ -550,8 +570,11 @@ struct PotrfStreams {
 // Order: TAIL(J) waits for HEAD(J) to be enqueued behind block J (event) and follows TAIL(J-1)
 // (stream order); HEAD(J) waits for TAIL(J-1), the last writer of the next block's columns.
 // diag_stage: scratch of np * 128 doubles (staged diagonal blocks, see potrf_panel_kernel)
+// batch > 1: `batch` matrices at A + c * cs (inv_diag and diag_stage likewise: all live in cell blocks `cs` doubles apart),
+// info words info_stride ints apart; every launch carries the cell index in blockIdx.y.
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
-                              double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr) {
+                              double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr, int batch = 1, int64_t cs = 0,
+                              int info_stride = 0) {
   const double* prev_stage = nullptr;
   double* prev_dst = nullptr;
   int prev_pw = 0;
@@ -559,7 +582,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     if (!prof) return;
     // algorithmic flops: 2 K per updated element (lower triangle incl. diagonal of the square part + rectangle)
     const double elems = 0.5 * (double)ncols_lower * (ncols_lower + 1) + (double)rows_rect * ncols;
-    (strip ? prof->strip_marks : prof->gemm_marks).push_back({prof->used, 2.0 * k * elems});
+    (strip ? prof->strip_marks : prof->gemm_marks).push_back({prof->used, 2.0 * k * elems * batch});
     hipEventRecord(prof->next(), s);
   };
   auto mark_end = [&](hipStream_t s) {
@@ -585,19 +608,19 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       double* stage_out = diag_stage + (int64_t)c * PW;
       if (pw == PW) {
         const int nchunks = (rows_below + PANEL128_ROWS - 1) / PANEL128_ROWS;
-        hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                           inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+        hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                           inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
       } else {
         if (tune.panel_rows == 256) {
           const int own = PanelGeom<4>::kOwnRows;
           const int nchunks = (rows_below + own - 1) / own;
-          hipLaunchKernelGGL(potrf_panel_kernel<4>, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+          hipLaunchKernelGGL(potrf_panel_kernel<4>, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
         } else {
           const int own = PanelGeom<2>::kOwnRows;
           const int nchunks = (rows_below + own - 1) / own;
-          hipLaunchKernelGGL(potrf_panel_kernel<2>, dim3(nchunks + 1), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw);
+          hipLaunchKernelGGL(potrf_panel_kernel<2>, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
+                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
         }
       }
       prev_stage = stage_out;
@@ -609,8 +632,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
         double* L21 = A + (int64_t)(c + pw) * lda + c;
         double* A22 = A + (int64_t)(c + pw) * lda + (c + pw);
         mark_gemm(st, strip, rows_below - strip, strip, pw, true);
-        hipError_t e = (pw == NB) ? launch_syrk_k64(st, rows_below, strip, L21, lda, A22, lda)
-                                  : launch_gemm(st, 0, 1, rows_below, strip, pw, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64);
+        hipError_t e = (pw == NB) ? launch_syrk_k64(st, rows_below, strip, L21, lda, A22, lda, batch, cs)
+                                  : launch_gemm(st, 0, 1, rows_below, strip, pw, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64,
+                                                batch, cs, cs, cs);
         mark_end(st);
         if (e != hipSuccess) return e;
       }
@@ -625,7 +649,8 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     {
       const int rows = total_rows - R;
       mark_gemm(st, wn, rows - wn, wn, w);
-      hipError_t e = launch_gemm(st, 0, 1, rows, wn, w, -1.0, Lpan, lda, Lpan, lda, 1.0, A + (int64_t)R * lda + R, lda, GEMM_C_LOWER, 64);
+      hipError_t e = launch_gemm(st, 0, 1, rows, wn, w, -1.0, Lpan, lda, Lpan, lda, 1.0, A + (int64_t)R * lda + R, lda, GEMM_C_LOWER,
+                                   batch > 1 ? tune.update_tile : 64, batch, cs, cs, cs);
       mark_end(st);
       if (e != hipSuccess) return e;
     }
@@ -638,7 +663,8 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       const int rows = total_rows - R2, cols = np - R2;
       const double* Lrow = A + (int64_t)R2 * lda + C;  // L[R2:, C:C+w]
       mark_gemm(ts, cols, rows - cols, cols, w);
-      hipError_t e = launch_gemm(ts, 0, 1, rows, cols, w, -1.0, Lrow, lda, Lrow, lda, 1.0, A + (int64_t)R2 * lda + R2, lda, GEMM_C_LOWER, tune.update_tile);
+      hipError_t e = launch_gemm(ts, 0, 1, rows, cols, w, -1.0, Lrow, lda, Lrow, lda, 1.0, A + (int64_t)R2 * lda + R2, lda, GEMM_C_LOWER,
+                                   tune.update_tile, batch, cs, cs, cs);
       mark_end(ts);
       if (e != hipSuccess) return e;
       if (ps) {
@@ -648,7 +674,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     }
   }
   // the last panel's diagonal block is still staged
-  if (prev_stage) hipLaunchKernelGGL(copy_block_kernel, dim3(1), dim3(256), 0, st, prev_stage, prev_dst, lda, prev_pw);
+  if (prev_stage) hipLaunchKernelGGL(copy_block_kernel, dim3(batch), dim3(256), 0, st, prev_stage, prev_dst, lda, prev_pw, cs);
   // everything later on `st` must see the aux stream's last update
   if (ps && tail_pending) hipStreamWaitEvent(st, ps->tail_done, 0);
   return hipGetLastError();

@@ -12,9 +12,12 @@ namespace gprx {
 //   workgroup j == i + 1 then forms x_{i+1} = invD_{i+1} b_{i+1}.
 // Step -1 (first launch) only forms x_0.  x overwrites b.
 __global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
-                                                     double* __restrict__ b, int i, int nblocks) {
+                                                     double* __restrict__ b, int i, int nblocks, int64_t cs) {
   __shared__ double sx[NB];
   __shared__ double sb[NB];
+  L += (int64_t)blockIdx.y * cs;  // batched: blockIdx.y = cell, cs = cell stride (0 for a single system)
+  inv_diag += (int64_t)blockIdx.y * cs;
+  b += (int64_t)blockIdx.y * cs;
   const int t = threadIdx.x;
   const int j = i + 1 + blockIdx.x;  // block row handled here
   if (j >= nblocks) return;
@@ -58,10 +61,13 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ 
 //   workgroup j == i - 1 then forms x_{i-1} = invD_{i-1}^T b_{i-1}.
 // Step i == nblocks only forms x_{nblocks-1}.
 __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
-                                                     double* __restrict__ b, int i, int nblocks) {
+                                                     double* __restrict__ b, int i, int nblocks, int64_t cs) {
   __shared__ double sx[NB];
   __shared__ double sb[NB];
   __shared__ double part[4][NB];
+  L += (int64_t)blockIdx.y * cs;
+  inv_diag += (int64_t)blockIdx.y * cs;
+  b += (int64_t)blockIdx.y * cs;
   const int tid = threadIdx.x;
   const int t = tid & 63, grp = tid >> 6;
   const int j = i - 1 - (int)blockIdx.x;
@@ -101,14 +107,15 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ 
   if (tid < NB) b[j * NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
-inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* b, int np, bool transpose) {
+inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* b, int np, bool transpose,
+                             int batch = 1, int64_t cs = 0) {
   const int nblocks = np / NB;
   if (!transpose) {
     for (int i = -1; i < nblocks - 1; ++i)
-      hipLaunchKernelGGL(trsv_fwd_step, dim3(i < 0 ? 1 : nblocks - 1 - i), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks);
+      hipLaunchKernelGGL(trsv_fwd_step, dim3(i < 0 ? 1 : nblocks - 1 - i, batch), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks, cs);
   } else {
     for (int i = nblocks; i >= 1; --i)
-      hipLaunchKernelGGL(trsv_bwd_step, dim3(i == nblocks ? 1 : i), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks);
+      hipLaunchKernelGGL(trsv_bwd_step, dim3(i == nblocks ? 1 : i, batch), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks, cs);
   }
   return hipGetLastError();
 }
@@ -187,8 +194,11 @@ inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, cons
 // ---- reductions ----------------------------------------------------------------------------------
 // out[0] = sum_i log L[i,i] (i < n), out[1] = sum_i v[i]^2 (i < n)
 __global__ __launch_bounds__(256) void logdet_quad_kernel(const double* __restrict__ L, int64_t lda, const double* __restrict__ v, int n,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, int64_t cs = 0, int out_stride = 0) {
   __shared__ double s0[4], s1[4];
+  L += (int64_t)blockIdx.x * cs;  // batched: blockIdx.x = cell
+  if (v) v += (int64_t)blockIdx.x * cs;
+  out += (int64_t)blockIdx.x * out_stride;
   double a = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     a += log(L[(int64_t)i * lda + i]);

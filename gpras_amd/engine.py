@@ -76,6 +76,31 @@ class Engine:
         check(self._lib.gprx_factorize(self._h, unit, ptr(theta), zp, mask, C.byref(loss)), self._h)
         return loss.value, None
 
+    def factorize_batch(self, units, thetas, mask: int):
+        """Exact models only: factorise ``len(units)`` cells -- cell ``i`` = output unit ``units[i]`` with
+        hyperparameters ``thetas[i]`` -- by one batched launch sequence (``gprx_factorize_batch``).  Returns
+        ``(losses, ok)``: the training losses (NaN where the kernel matrix was not positive definite) and a boolean
+        array; the factorisations stay resident in slots ``0..len(units)-1`` (see ``select_slot``)."""
+        units = np.ascontiguousarray(units, dtype=np.int32)
+        thetas = as_f64(thetas)
+        if thetas.shape != (units.size, self.n_theta):
+            raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
+        losses = np.empty(units.size)
+        status = np.zeros(units.size, dtype=np.int32)
+        rc = self._lib.gprx_factorize_batch(self._h, units.size, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status))
+        if rc not in (_lib.GPRX_OK, _lib.GPRX_ENOTPD):
+            check(rc, self._h)
+        return losses, status == 0
+
+    def select_slot(self, slot: int):
+        """Make slot ``slot`` of the last ``factorize_batch`` the current factorisation (for ``predict``)."""
+        check(self._lib.gprx_select_slot(self._h, int(slot)), self._h)
+
+    def last_batch_ms(self) -> float:
+        ms = C.c_double()
+        check(self._lib.gprx_last_batch_ms(self._h, C.byref(ms)), self._h)
+        return ms.value
+
     def predict(self, xs, include_noise: bool = True):
         """Mean and variance at ``xs`` for the unit factorised by the last ``objective`` call."""
         xs = as_f64(xs)

@@ -102,6 +102,19 @@ int gprx_factorize(gprx_handle h, int unit, const double* theta, const double* z
  * Replaces a Python loop of gprx_factorize calls; each handle is left factorised as by gprx_factorize. */
 int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const double* thetas, int mask, double* losses);
 
+/* Batched cells on ONE handle: `count` exact factorisations -- cell i = (units[i], thetas[i]), all on the handle's x,
+ * which is what the reference's per-mode loop (gpr.py:272-274, 336-339), its multi-start (gpr.py:149-176) and its
+ * differential-evolution population (gpr.py:178-207) evaluate one after the other.  Every kernel of the factorisation
+ * is launched once for all cells (cell index in the grid), so small matrices still fill the GPU.  thetas: (count,
+ * n_theta); losses (may be NULL): count training losses, NaN for a cell whose matrix is not positive definite; status
+ * (may be NULL): per-cell GPRX_OK / GPRX_ENOTPD.  Returns GPRX_ENOTPD if any cell failed (the others are valid).
+ * Results are bit-identical to gprx_factorize on each cell.  The factorisations stay resident in slots 0..count-1
+ * until the next batch; gprx_select_slot makes one of them current for gprx_predict / gprx_predict_dev. */
+int gprx_factorize_batch(gprx_handle h, int count, const int* units, const double* thetas, int mask, double* losses, int* status);
+int gprx_select_slot(gprx_handle h, int slot);
+/* device time (ms) of the last gprx_factorize_batch, HIP events on the handle's stream around the whole batch */
+int gprx_last_batch_ms(gprx_handle h, double* ms);
+
 /* SGPR.predict_y (gpr.py:336-339): predictive mean and variance at xs (ns, d) for the unit
  * factorised last.  include_noise != 0 adds the likelihood variance (predict_y); 0 gives
  * predict_f.  mean/var: ns values each. */

@@ -128,3 +128,73 @@ def test_factorize_many_matches_single_calls_and_replays(lib):
     finally:
         for c in range(cells):
             lib.gprx_destroy(C.c_void_p(handles[c]))
+
+
+@pytest.mark.parametrize("kernel,n,d,ard,cells", [("RBF", 700, 5, False, 5), ("Matern52", 1100, 8, True, 3), ("Matern12", 130, 2, False, 17)])
+def test_factorize_batch_bit_identical_and_selectable(lib, kernel, n, d, ard, cells):
+    """gprx_factorize_batch: every kernel of the schedule launched once for all cells.  Losses must equal the
+    single-cell call bit for bit (same kernels, same operation order per element), match the oracle to 1e-9, and
+    each slot must be usable for predict after gprx_select_slot -- also after the arena has grown."""
+    x, y, xs = make_regression(n, d, n_outputs=3, n_test=50, config=11, unit=n)
+    h = make_handle(lib, n, d, kernel, ard, x, y)
+    nt = 2 + (d if ard else 1)
+    try:
+        rng = np.random.default_rng(3)
+        for count in (2, cells):  # second round grows the arena
+            units = np.ascontiguousarray(rng.integers(0, 3, size=count), dtype=np.int32)
+            thetas = np.ascontiguousarray(rng.normal(0.3, 0.3, size=(count, nt)))
+            losses = np.zeros(count)
+            status = np.zeros(count, dtype=np.int32)
+            check(lib.gprx_factorize_batch(h, count, ptr(units), ptr(thetas), ALL, ptr(losses), ptr(status)), h)
+            assert not status.any()
+            # slots first (a single-cell call below would not disturb them, but keep the order strict)
+            preds = []
+            for c in range(count):
+                check(lib.gprx_select_slot(h, c), h)
+                mean, var = np.zeros(50), np.zeros(50)
+                check(lib.gprx_predict(h, ptr(xs), 50, ptr(mean), ptr(var), 1), h)
+                preds.append((mean, var))
+            for c in range(count):
+                th = thetas[c]
+                wl = th[1:-1] if ard else float(th[1])
+                ref = oex.loss(kernel, x, y[:, units[c]], float(th[0]), wl, float(th[-1]))
+                assert abs(losses[c] - ref) <= 1e-9 * abs(ref)
+                v, l, s = otr.constrain(th[0], wl, th[-1])
+                rm, rv = oex.predict(kernel, x, y[:, units[c]], float(v), l, float(s), xs)
+                mean, var = preds[c]
+                assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
+            for c in range(count):
+                single = C.c_double()
+                check(lib.gprx_factorize(h, int(units[c]), ptr(np.ascontiguousarray(thetas[c])), None, ALL, C.byref(single)), h)
+                assert single.value == losses[c]
+        assert lib.gprx_select_slot(h, 99) == _lib.GPRX_EINVAL
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_factorize_batch_reports_failed_cells(lib):
+    """A cell whose kernel matrix is numerically singular (duplicated rows, noise at its floor) fails alone."""
+    n, d = 256, 3
+    x, y, _ = make_regression(n, d, config=1, unit=1)
+    x[1::2] = x[0::2]  # duplicated inputs
+    h = make_handle(lib, n, d, "RBF", False, x, y)
+    try:
+        good = pack_theta(1.0, 0.9, 0.1)
+        bad = good.copy()
+        bad[0] = 40.0   # variance ~ 40
+        bad[-1] = -800.0  # noise -> 1e-6: K has exactly repeated rows up to 1e-6 on the diagonal, variance 40 -> pivot <= 0 in fp64
+        bad[1] = 50.0
+        thetas = np.ascontiguousarray(np.stack([good, bad, good]))
+        units = np.zeros(3, dtype=np.int32)
+        losses = np.zeros(3)
+        status = np.zeros(3, dtype=np.int32)
+        rc = lib.gprx_factorize_batch(h, 3, ptr(units), ptr(thetas), ALL, ptr(losses), ptr(status))
+        ref = oex.loss("RBF", x, y[:, 0], float(good[0]), float(good[1]), float(good[2]))
+        assert abs(losses[0] - ref) <= 1e-9 * abs(ref) and losses[2] == losses[0]
+        if rc == _lib.GPRX_ENOTPD:
+            assert status[1] == _lib.GPRX_ENOTPD and status[0] == 0 and status[2] == 0 and np.isnan(losses[1])
+            assert lib.gprx_select_slot(h, 1) == _lib.GPRX_ESTATE
+        else:
+            assert rc == _lib.GPRX_OK
+    finally:
+        lib.gprx_destroy(h)
