@@ -25,7 +25,12 @@ namespace gprx {
 
 #ifdef GPRX_PANEL_STAMPS
 __device__ unsigned long long g_panel_stamps[64];
-#define PSTAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_panel_stamps[i] = __builtin_amdgcn_s_memtime();
+#define PSTAMP(i)                                                                                                     \
+  if (threadIdx.x == 0) {                                                                                             \
+    if (blockIdx.x == 0) g_panel_stamps[i] = __builtin_amdgcn_s_memtime();                                            \
+    if (blockIdx.x == gridDim.x / 2 && (i) < 6) g_panel_stamps[32 + (i)] = __builtin_amdgcn_s_memtime();               \
+    if (blockIdx.x == gridDim.x - 2 && (i) < 6) g_panel_stamps[48 + (i)] = __builtin_amdgcn_s_memtime();               \
+  }
 #else
 #define PSTAMP(i)
 #endif
@@ -107,8 +112,10 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[RT][4], PanelCtx& c) {
       for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], l[k][m], t);
       x[k] = (C0 + k > c.zero_above) ? 0.0 : t * rinv[k];
     }
+    if constexpr (P == 1) { PSTAMP(16) }
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.sX[c.tid * PSUB + k] = x[k];
+    if constexpr (P == 1) { PSTAMP(17) }
     // solved values leave through memory directly (64 contiguous bytes per row and sub-panel): no 66-KiB output
     // image in LDS, so several panel workgroups -- of this or of other cells -- fit on one CU beside GEMM tiles
     if (c.out) {
@@ -222,33 +229,50 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   }
   PSTAMP(0)
 
-  // ---- load straight into the accumulator layout (32 loads per lane, all in flight) ----
+  // ---- load straight into the accumulator layout: 16 RT loads per lane, all in flight ----
+  // Every load is unconditional (rows outside the matrix read row 0 of the diagonal block instead) and the
+  // triangle / padding / identity masks are applied afterwards with selects: with the conditions around the
+  // loads the compiler emitted a branch and a full wait per load, i.e. 32 serialised memory round trips.
   d4 acc[RT][4];
+  {
+    const double* rowp[RT][4];
+    bool valid[RT][4];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int wrow = WROWS * c.wave + 16 * rt + c.g + 4 * q;  // workgroup row
-      const double* src = nullptr;
-      if (wrow < NB) {
-        src = A + (int64_t)wrow * lda;
-      } else if (!last) {
-        const int idx = blockIdx.x * PANEL_ROWS + (wrow - NB);
-        if (idx < rows_below) src = A + (int64_t)(NB + idx) * lda;
+      for (int q = 0; q < 4; ++q) {
+        const int wrow = WROWS * c.wave + 16 * rt + c.g + 4 * q;  // workgroup row
+        const int idx = (int)blockIdx.x * PANEL_ROWS + (wrow - NB);
+        const bool diag = wrow < NB;
+        const bool ok = diag || (!last && idx < rows_below);
+        const int64_t mrow = diag ? wrow : (ok ? NB + idx : 0);
+        rowp[rt][q] = A + mrow * lda + c.r;
+        valid[rt][q] = ok;
       }
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const int col = kt * 16 + c.r;
-        double v = 0.0;
-        if (src) v = src[col];
-        if (wrow < NB) {
-          if (col > wrow) v = 0.0;
-        } else if (last) {
-          v = (col == wrow - NB) ? 1.0 : 0.0;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = rowp[rt][q][kt * 16];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int wrow = WROWS * c.wave + 16 * rt + c.g + 4 * q;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const int col = kt * 16 + c.r;
+          double v = valid[rt][q] ? acc[rt][kt][q] : 0.0;
+          if (wrow < NB) {
+            v = (col > wrow) ? 0.0 : v;
+          } else if (last) {
+            v = (col == wrow - NB) ? 1.0 : 0.0;
+          }
+          acc[rt][kt][q] = v;
         }
-        acc[rt][kt][q] = v;
       }
-    }
+  }
   PSTAMP(1)
 
   panel_step<0, RT>(acc, c);
@@ -529,6 +553,7 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_OUTER_BLOCK")) v.outer_block = atoi(e);  // experiments without recompiling callers
     if (const char* e = getenv("GPRX_UPDATE_TILE")) v.update_tile = atoi(e);
     if (const char* e = getenv("GPRX_PANEL_ROWS")) v.panel_rows = atoi(e);
+    if (const char* e = getenv("GPRX_PANEL_WIDTH")) v.panel_width = atoi(e);
     return v;
   }();
   return t;
