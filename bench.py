@@ -5,11 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = every one of the rank's CELLS_PER_STEP independent cells fitted once (F1) at fixed
-hyperparameters, all enqueued before any is awaited (gprx_factorize_many); per cell: stationary-kernel matrix build
-(lower tiles) + blocked fp64-MFMA Cholesky with y carried as an extra row + backward solve for alpha +
-log marginal likelihood returned to the host -- BASELINE.json configs[1] ("Single cell, N=4096 d=8
-RBF fp64 on 1 MI355X: HIP kernel build + blocked MFMA Cholesky").  Inputs are resident in HBM when the
-timed region starts.  With N > 1 ranks every rank fits its own cells (independent units, SURVEY.md
+hyperparameters by ONE batched launch sequence (gprx_factorize_batch: the cell index rides in every launch's
+grid); per cell: stationary-kernel matrix build (lower tiles) + blocked fp64-MFMA Cholesky with y carried as an
+extra row + backward solve for alpha + log marginal likelihood returned to the host -- BASELINE.json configs[1]
+("Single cell, N=4096 d=8 RBF fp64 on 1 MI355X: HIP kernel build + blocked MFMA Cholesky").  The cells are the
+reference's own unit of independent work: the per-mode models of one GPRAS (gpr.py:272-274) share x and differ in y
+and hyperparameters; here every cell has its own y column and its own hyperparameters, so nothing is shared between
+cells but the inputs x.  Inputs are resident in HBM when the timed region starts.  With N > 1 ranks every rank fits its own cells (independent units, SURVEY.md
 section 8e: no data-path collective) and one RCCL all_gather collects the results at the end; the
 reported value is all ranks' fits divided by the slowest rank's time ("weak" scaling).
 
@@ -38,7 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_TRAIN, DIM, N_TEST = 4096, 8, 100_000
-CELLS_PER_STEP = 16  # independent cells in flight per GPU per step (measured: 8 -> 652, 12 -> 747, 16 -> 784 fits/s)
+CELLS_PER_STEP = 32  # cells per batched launch sequence per GPU per step (measured: 1 -> 400, 8 -> 1140, 16 -> 1530, 32 -> 1650 fits/s)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz: half the f32 matrix rate of MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -46,7 +48,7 @@ HBM_PEAK_GBS = 8000.0
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be read
     inside this process); None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
@@ -98,40 +100,36 @@ def main():
     device = local_rank if distributed else 0
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
-    # One handle per cell (own X, y, workspaces, stream), all resident in HBM before the timed region.
+    # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
     from gpras_amd.model import NOISE_LOWER, softplus_inv
 
     cells = max(1, args.cells)
-    handles = (C.c_void_p * cells)()
-    x = y = xs = None
-    for c in range(cells):
-        xc, yc, xsc = make_regression(N_TRAIN, DIM, n_outputs=1, n_test=N_TEST if c == 0 else 0, config=2, unit=rank * cells + c)
-        hc = C.c_void_p()
-        check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(hc)))
-        check(lib.gprx_set_data(hc, ptr(xc), ptr(yc), 1), hc)
-        handles[c] = hc
-        if c == 0:
-            x, y, xs = xc, yc, xsc
-    h = C.c_void_p(handles[0])
-    # reference initial values: variance 1, lengthscale mean|x|, noise 1 (gpr.py:289, :298)
+    x, y, xs = make_regression(N_TRAIN, DIM, n_outputs=cells, n_test=N_TEST if rank == 0 else 0, config=2, unit=rank)
+    h = C.c_void_p()
+    check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+    # reference initial values: variance 1, lengthscale mean|x|, noise 1 (gpr.py:289, :298); the cells' hyperparameters
+    # are spread around them (cell 0 keeps them exactly), so every cell builds and factors a different matrix
     theta = np.ascontiguousarray([softplus_inv(1.0), softplus_inv(np.mean(np.abs(x))), softplus_inv(1.0 - NOISE_LOWER)], dtype=np.float64)
-    thetas = np.ascontiguousarray(np.tile(theta, (cells, 1)))
-    units = np.zeros(cells, dtype=np.int32)
+    spread = np.random.default_rng(2000 + rank).uniform(-0.15, 0.15, size=(cells, 3))
+    spread[0] = 0.0
+    thetas = np.ascontiguousarray(theta[None, :] + spread)
+    units = np.arange(cells, dtype=np.int32)
     losses = np.zeros(cells)
+    status = np.zeros(cells, dtype=np.int32)
     mask = 7
     loss = C.c_double()
 
     def sync_all():
-        for c in range(cells):
-            check(lib.gprx_synchronize(C.c_void_p(handles[c])))
+        check(lib.gprx_synchronize(h), h)
         if distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
     def fit_step():
-        # one step: every cell of this rank fitted once (all enqueued, then awaited)
-        check(lib.gprx_factorize_many(cells, handles, ptr(units), ptr(thetas), mask, ptr(losses)))
+        # one step: every cell of this rank fitted once by one batched launch sequence
+        check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status)), h)
 
     def fit_one():
         check(lib.gprx_factorize(h, 0, ptr(theta), None, mask, C.byref(loss)), h)
@@ -169,43 +167,46 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1] as the many-independent-cells workload: exact GP N=4096 d=8 RBF, fit F1 = kernel build + blocked fp64-MFMA Cholesky + alpha + LML, per cell",
+            "workload": "BASELINE configs[1] as the many-independent-cells workload: exact GP N=4096 d=8 RBF, fit F1 = kernel build + blocked fp64-MFMA Cholesky + alpha + LML, per cell; cells = y columns of one training set with per-cell hyperparameters (the reference's per-mode models)",
             "n_train": N_TRAIN,
             "d": DIM,
             "kernel": "RBF",
             "cells_per_gpu_per_step": cells,
-            "parallelism": f"{cells} independent cells in flight per GPU x {world} GPU, one RCCL all_gather at the end",
+            "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end",
         },
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: instrumented pass, HIP events around every launch ----
+        # ---- roofline of the dominant kernel: instrumented pass over the same batched step, HIP events around every launch ----
         check(lib.gprx_set_profiling(h, 1), h)
         prof = (C.c_double * 8)()
         acc = np.zeros(8)
         reps = 3
         for _ in range(reps):
-            fit_one()
+            fit_step()
             lib.gprx_last_profile(h, prof)
             acc += np.array(list(prof))
         check(lib.gprx_set_profiling(h, 0), h)
         gemm_ms, gemm_launches, gemm_flops, panel_ms, panel_launches, strip_ms, strip_launches, strip_flops = acc / reps
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "gprx::gemm_f64_kernel<0,1,64,64> (Cholesky bulk trailing update A22 -= L21 L21^T, K = 1024: HEAD + TAIL launches)",
+            "kernel": f"gprx::gemm_f64_kernel<0,1,64,64> (Cholesky bulk trailing update A22 -= L21 L21^T of all {cells} cells per launch, K = 1024: HEAD + TAIL launches)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": pmc_traffic("gemm_f64_kernel<0,1,64,64>"),
-            "launches_per_fit": gemm_launches,
+            "launches_per_step": gemm_launches,
             "avg_launch_us": 1e3 * gemm_ms / gemm_launches,
-            "algorithmic_flops_per_fit": gemm_flops,
-            "panel_kernel_avg_us": 1e3 * panel_ms / panel_launches,
-            "strip_kernel": {"launches_per_fit": strip_launches, "avg_launch_us": 1e3 * strip_ms / max(strip_launches, 1), "tflops": strip_flops / (strip_ms * 1e-3) / 1e12 if strip_ms else None},
-            "cholesky_flops_per_fit": N_TRAIN**3 / 3,
+            "algorithmic_flops_per_launch": gemm_flops / gemm_launches,
+            "algorithmic_flops_per_step": gemm_flops,
+            "panel_kernel": {"launches_per_step": panel_launches, "avg_launch_us": 1e3 * panel_ms / panel_launches},
+            "inblock_update_kernels": {"launches_per_step": strip_launches, "avg_launch_us": 1e3 * strip_ms / max(strip_launches, 1), "tflops": strip_flops / (strip_ms * 1e-3) / 1e12 if strip_ms else None},
+            "cholesky_flops_per_step": cells * N_TRAIN**3 / 3,
+            "whole_step_tflops": cells * N_TRAIN**3 / 3 / (elapsed / args.steps) / 1e12,
         }
+        fit_one()
         ms = (C.c_double * 4)()
         lib.gprx_last_timings(h, ms)
         kmat_bytes = 8.0 * (N_TRAIN * (N_TRAIN + 64) / 2) + 8.0 * N_TRAIN * DIM
@@ -248,7 +249,7 @@ def main():
 
         g3 = GPRAS("Matern52", device=device)
         t1 = time.perf_counter()
-        g3.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
+        g3.fit(x, y[:, :1], None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
         t3 = time.perf_counter() - t1
         extra["F3_lbfgs50_matern52_ard_seconds"] = t3
         extra["F3_evaluations"] = g3.models[0].n_evals
@@ -302,14 +303,15 @@ def main():
             "predict_points_per_s": 2000 / tcp,
             "host_cpu_count": cores,
         }
+        fit_step()
         result["parity_at_bench_size"] = {
+            "batched_cell0_equals_single_call_bitwise": bool(losses[0] == loss.value),
             "loss_rel_err_vs_oracle": abs(loss.value - gpu_loss_check) / abs(gpu_loss_check),
             "predict_mean_rel_err": float(np.max(np.abs(gpu_mean - cm)) / np.max(np.abs(cm))),
             "predict_var_rel_err": float(np.max(np.abs(gpu_var - cv) / cv)),
         }
 
-    for c in range(cells):
-        lib.gprx_destroy(C.c_void_p(handles[c]))
+    lib.gprx_destroy(h)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -286,40 +286,42 @@ int exact_factorize_replay(gprx_handle h, int unit, const Theta& t) {
   return GPRX_OK;
 }
 
+void summarize_profile(gprx_handle h) {
+  double gemm_ms = 0.0, gemm_flops = 0.0, panel_ms = 0.0;
+  for (auto& mk : h->prof.gemm_marks) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
+    gemm_ms += ms;
+    gemm_flops += mk.second;
+  }
+  for (auto idx : h->prof.panel_marks) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->prof.pool[idx], h->prof.pool[idx + 1]);
+    panel_ms += ms;
+  }
+  h->prof_out[0] = gemm_ms;
+  h->prof_out[1] = (double)h->prof.gemm_marks.size();
+  h->prof_out[2] = gemm_flops;
+  h->prof_out[3] = panel_ms;
+  h->prof_out[4] = (double)h->prof.panel_marks.size();
+  double strip_ms = 0.0, strip_flops = 0.0;
+  for (auto& mk : h->prof.strip_marks) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
+    strip_ms += ms;
+    strip_flops += mk.second;
+  }
+  h->prof_out[5] = strip_ms;
+  h->prof_out[6] = (double)h->prof.strip_marks.size();
+  h->prof_out[7] = strip_flops;
+}
+
 int exact_factorize_finish(gprx_handle h, double* lml_out) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const double* red = h->pin + 64;
   int info = 0;
   std::memcpy(&info, h->pin + 72, sizeof(int));
-  if (h->profiling) {
-    double gemm_ms = 0.0, gemm_flops = 0.0, panel_ms = 0.0;
-    for (auto& mk : h->prof.gemm_marks) {
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
-      gemm_ms += ms;
-      gemm_flops += mk.second;
-    }
-    for (auto idx : h->prof.panel_marks) {
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, h->prof.pool[idx], h->prof.pool[idx + 1]);
-      panel_ms += ms;
-    }
-    h->prof_out[0] = gemm_ms;
-    h->prof_out[1] = (double)h->prof.gemm_marks.size();
-    h->prof_out[2] = gemm_flops;
-    h->prof_out[3] = panel_ms;
-    h->prof_out[4] = (double)h->prof.panel_marks.size();
-    double strip_ms = 0.0, strip_flops = 0.0;
-    for (auto& mk : h->prof.strip_marks) {
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
-      strip_ms += ms;
-      strip_flops += mk.second;
-    }
-    h->prof_out[5] = strip_ms;
-    h->prof_out[6] = (double)h->prof.strip_marks.size();
-    h->prof_out[7] = strip_flops;
-  }
+  if (h->profiling) summarize_profile(h);
   if (info != 0) {
     h->factorized = false;
     char msg[128];
@@ -444,8 +446,9 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
   hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, count), dim3(256), 0, st, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p,
                      (const double*)h->cellpar.p, (int)h->n, np, NB, cs);
   int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
-  HIPCHK(h, potrf_lower(st, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, nullptr, lookahead ? &h->pstreams : nullptr, count, cs,
-                        2 * CELL_RES));
+  if (h->profiling) h->prof.reset();
+  HIPCHK(h, potrf_lower(st, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr,
+                        lookahead ? &h->pstreams : nullptr, count, cs, 2 * CELL_RES));
   const double* beta = K0 + (int64_t)np * ld;
   hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, count), dim3(256), 0, st, beta, K0 + h->off_alpha, np, cs);
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)K0, ld, beta, np, h->cellres.p, cs, CELL_RES);
@@ -456,6 +459,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
   float ms = 0.f;
   hipEventElapsedTime(&ms, h->bev[0], h->bev[1]);
   h->batch_ms = ms;
+  if (h->profiling) summarize_profile(h);
   int first_error = GPRX_OK;
   for (int c = 0; c < count; ++c) {
     int info = 0;
@@ -1207,6 +1211,8 @@ int gprx_set_tuning(const char* key, int value) {
   else if (k == "update_tile" && (value == 0 || value == 64 || value == 128)) t.update_tile = value;
   else if (k == "no_lookahead") t.no_lookahead = value != 0;
   else if (k == "panel_rows" && (value == 0 || value == 128 || value == 256)) t.panel_rows = value;
+  else if (k == "panel_occ" && (value == 0 || value == 2 || value == 3)) t.panel_occ = value;
+  else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
   return GPRX_OK;
 }

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void copy_block_kernel(const double* __restric
   flush_staged_block(stage + (int64_t)blockIdx.x * cs, dst + (int64_t)blockIdx.x * cs, lda, pw, threadIdx.x);
 }
 
-template <int RT>
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
+template <int RT, int OCC>
+__global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
                                                           double* __restrict__ inv_diag, int* __restrict__ info, int col0,
                                                           double* __restrict__ stage_out, const double* __restrict__ prev_stage,
                                                           double* __restrict__ prev_dst, int prev_pw, int64_t cs, int info_stride) {
@@ -546,6 +546,8 @@ struct PotrfTuning {
   int update_tile = 0;   // tile of the TAIL GEMM: 64 or 128
   int no_lookahead = 0;  // 1: everything on the main stream (debugging)
   int panel_rows = 0;    // rows per panel workgroup: 128 (default) or 256
+  int panel_occ = 0;     // 3: panel kernel compiled for 3 workgroups per CU (168 registers, small spills) instead of 2
+  int inblock = 0;       // 1: right-looking K = 64 strips inside an outer block instead of the recursive halving
 };
 inline PotrfTuning& potrf_tuning() {
   static PotrfTuning t = [] {
@@ -554,6 +556,8 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_UPDATE_TILE")) v.update_tile = atoi(e);
     if (const char* e = getenv("GPRX_PANEL_ROWS")) v.panel_rows = atoi(e);
     if (const char* e = getenv("GPRX_PANEL_WIDTH")) v.panel_width = atoi(e);
+    if (const char* e = getenv("GPRX_PANEL_OCC")) v.panel_occ = atoi(e);
+    if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
     return v;
   }();
   return t;
@@ -618,53 +622,84 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   if (tune.no_lookahead) ps = nullptr;
   const int ob = tune.outer_block ? tune.outer_block : (np > 4096 ? 512 : 1024);  // measured: N=2048/4096 -> 1024, N=8192/16384 -> 512
   const int pwidth = tune.panel_width ? tune.panel_width : NB;
+  // bulk-update tile: batched cells fill the chip with 64 x 64 tiles already (4 workgroups per CU hide the C
+  // read-modify-write; measured 1529 vs 1513 fits/s at 16 cells of N = 4096); a single matrix lets launch_gemm choose
+  const int bulk_tile = tune.update_tile ? tune.update_tile : (batch > 1 ? 64 : 0);
   bool tail_pending = false;
+  hipError_t err = hipSuccess;
+  // one panel: factor the diagonal block at column c and solve every row below it
+  auto panel = [&](int c, int pw) {
+    const int rows_below = total_rows - c - pw;
+    double* Acc = A + (int64_t)c * lda + c;
+    if (prof) {
+      prof->panel_marks.push_back(prof->used);
+      hipEventRecord(prof->next(), st);
+    }
+    double* stage_out = diag_stage + (int64_t)c * PW;
+    double* invd = inv_diag + (int64_t)(c / NB) * NB * NB;
+    if (pw == PW) {
+      const int nchunks = (rows_below + PANEL128_ROWS - 1) / PANEL128_ROWS;
+      hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, c,
+                         stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+    } else if (tune.panel_rows == 256) {
+      const int own = PanelGeom<4>::kOwnRows;
+      const int nchunks = (rows_below + own - 1) / own;
+      hipLaunchKernelGGL((potrf_panel_kernel<4, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, c,
+                         stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+    } else {
+      const int own = PanelGeom<2>::kOwnRows;
+      const int nchunks = (rows_below + own - 1) / own;
+      if (tune.panel_occ == 3)
+        hipLaunchKernelGGL((potrf_panel_kernel<2, 3>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
+                           c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+      else
+        hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
+                           c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+    }
+    prev_stage = stage_out;
+    prev_dst = Acc;
+    prev_pw = pw;
+    if (prof) hipEventRecord(prof->next(), st);
+  };
+  // in-block update: columns [c1, c1 + n) and every row from c1 down, by the k columns [c0, c0 + k) factored before
+  auto inblock_update = [&](int c0, int k, int c1, int n) {
+    const int rows = total_rows - c1;
+    const double* L21 = A + (int64_t)c1 * lda + c0;
+    double* A22 = A + (int64_t)c1 * lda + c1;
+    mark_gemm(st, n, rows - n, n, k, true);
+    hipError_t e = (k == NB) ? launch_syrk_k64(st, rows, n, L21, lda, A22, lda, batch, cs)
+                             : launch_gemm(st, 0, 1, rows, n, k, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64, batch, cs, cs, cs);
+    mark_end(st);
+    if (e != hipSuccess && err == hipSuccess) err = e;
+  };
+  // Inside an outer block the panels are combined recursively: factor the left half, update the right half with
+  // it (K = half the width), factor the right half.  The block's columns are rewritten log2(w / 64) times
+  // instead of w / 64 times (a K = 64 update moves 16 bytes of C per 128 flops -- the strips were HBM-bound once
+  // many cells are batched), and most in-block flops run at K >= 128.  tune.inblock == 1: the old right-looking
+  // strips (every panel followed by a K = 64 update of all remaining columns of the block).
+  auto factor_range = [&](auto&& self, int c0, int w) -> void {
+    const int base = (pwidth == PW && w == PW) ? PW : NB;
+    if (w <= base) {
+      panel(c0, w);
+      return;
+    }
+    const int h = ((w / NB + 1) / 2) * NB;
+    self(self, c0, h);
+    inblock_update(c0, h, c0 + h, w - h);
+    self(self, c0 + h, w - h);
+  };
   for (int C = 0; C < np; C += ob) {
     const int w = (np - C < ob) ? np - C : ob;
-    int c = C;
-    while (c < C + w) {
-      const int pw = (pwidth == PW && C + w - c >= PW) ? PW : NB;  // 128-column panel, or 64 columns
-      const int rows_below = total_rows - c - pw;
-      double* Acc = A + (int64_t)c * lda + c;
-      if (prof) {
-        prof->panel_marks.push_back(prof->used);
-        hipEventRecord(prof->next(), st);
+    if (tune.inblock == 1) {
+      for (int c = C; c < C + w; c += NB) {
+        panel(c, NB);
+        const int strip = C + w - c - NB;
+        if (strip > 0) inblock_update(c, NB, c + NB, strip);
       }
-      double* stage_out = diag_stage + (int64_t)c * PW;
-      if (pw == PW) {
-        const int nchunks = (rows_below + PANEL128_ROWS - 1) / PANEL128_ROWS;
-        hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                           inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
-      } else {
-        if (tune.panel_rows == 256) {
-          const int own = PanelGeom<4>::kOwnRows;
-          const int nchunks = (rows_below + own - 1) / own;
-          hipLaunchKernelGGL(potrf_panel_kernel<4>, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
-        } else {
-          const int own = PanelGeom<2>::kOwnRows;
-          const int nchunks = (rows_below + own - 1) / own;
-          hipLaunchKernelGGL(potrf_panel_kernel<2>, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks,
-                             inv_diag + (int64_t)(c / NB) * NB * NB, info, c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
-        }
-      }
-      prev_stage = stage_out;
-      prev_dst = Acc;
-      prev_pw = pw;
-      if (prof) hipEventRecord(prof->next(), st);
-      const int strip = C + w - c - pw;  // remaining columns of this outer block
-      if (strip > 0) {
-        double* L21 = A + (int64_t)(c + pw) * lda + c;
-        double* A22 = A + (int64_t)(c + pw) * lda + (c + pw);
-        mark_gemm(st, strip, rows_below - strip, strip, pw, true);
-        hipError_t e = (pw == NB) ? launch_syrk_k64(st, rows_below, strip, L21, lda, A22, lda, batch, cs)
-                                  : launch_gemm(st, 0, 1, rows_below, strip, pw, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64,
-                                                batch, cs, cs, cs);
-        mark_end(st);
-        if (e != hipSuccess) return e;
-      }
-      c += pw;
+    } else {
+      factor_range(factor_range, C, w);
     }
+    if (err != hipSuccess) return err;
     const int R = C + w;  // first column right of this block
     if (R >= np) break;
     const int wn = (np - R < ob) ? np - R : ob;     // width of the next block
@@ -675,7 +710,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       const int rows = total_rows - R;
       mark_gemm(st, wn, rows - wn, wn, w);
       hipError_t e = launch_gemm(st, 0, 1, rows, wn, w, -1.0, Lpan, lda, Lpan, lda, 1.0, A + (int64_t)R * lda + R, lda, GEMM_C_LOWER,
-                                   batch > 1 ? tune.update_tile : 64, batch, cs, cs, cs);
+                                   batch > 1 ? bulk_tile : 64, batch, cs, cs, cs);
       mark_end(st);
       if (e != hipSuccess) return e;
     }
@@ -689,7 +724,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       const double* Lrow = A + (int64_t)R2 * lda + C;  // L[R2:, C:C+w]
       mark_gemm(ts, cols, rows - cols, cols, w);
       hipError_t e = launch_gemm(ts, 0, 1, rows, cols, w, -1.0, Lrow, lda, Lrow, lda, 1.0, A + (int64_t)R2 * lda + R2, lda, GEMM_C_LOWER,
-                                   tune.update_tile, batch, cs, cs, cs);
+                                   bulk_tile, batch, cs, cs, cs);
       mark_end(ts);
       if (e != hipSuccess) return e;
       if (ps) {
