@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=CELLS_PER_STEP, help="independent cells per GPU per step")
     ap.add_argument("--no-extras", action="store_true", help="skip F2/F3/predict/cpu legs (profiling runs)")
+    ap.add_argument("--batched-only", action="store_true", help="profiling runs: no single-cell calls either, so every launch in a trace belongs to a batched step")
     return ap.parse_args()
 
 
@@ -190,22 +191,23 @@ def main():
         gemm_ms, gemm_launches, gemm_flops, panel_ms, panel_launches, strip_ms, strip_launches, strip_flops = acc / reps
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": f"gprx::gemm_f64_kernel<0,1,64,64> (Cholesky bulk trailing update A22 -= L21 L21^T of all {cells} cells per launch, K = 1024: HEAD + TAIL launches)",
+            "kernel": f"gprx::gemm_f64_kernel<0,1,64,64,0>: every launch of the Cholesky's main update kernel A22 -= L21 L21^T in a step, all {cells} cells per launch (5 bulk HEAD/TAIL updates with K = 1024 + 12 in-block updates with K = 256 / 512)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": pmc_traffic("gemm_f64_kernel<0,1,64,64>"),
+            "traffic": pmc_traffic("gemm_f64_kernel<0,1,64,64,0>"),
             "launches_per_step": gemm_launches,
             "avg_launch_us": 1e3 * gemm_ms / gemm_launches,
             "algorithmic_flops_per_launch": gemm_flops / gemm_launches,
             "algorithmic_flops_per_step": gemm_flops,
             "panel_kernel": {"launches_per_step": panel_launches, "avg_launch_us": 1e3 * panel_ms / panel_launches},
-            "inblock_update_kernels": {"launches_per_step": strip_launches, "avg_launch_us": 1e3 * strip_ms / max(strip_launches, 1), "tflops": strip_flops / (strip_ms * 1e-3) / 1e12 if strip_ms else None},
+            "short_k_inblock_updates": {"kernels": "syrk_k64_kernel (K = 64), gemm_f64_kernel<0,1,64,64,1> (K = 128)", "launches_per_step": strip_launches, "avg_launch_us": 1e3 * strip_ms / max(strip_launches, 1), "tflops": strip_flops / (strip_ms * 1e-3) / 1e12 if strip_ms else None},
             "cholesky_flops_per_step": cells * N_TRAIN**3 / 3,
             "whole_step_tflops": cells * N_TRAIN**3 / 3 / (elapsed / args.steps) / 1e12,
         }
+    if rank == 0 and not args.batched_only:
         fit_one()
         ms = (C.c_double * 4)()
         lib.gprx_last_timings(h, ms)
@@ -219,7 +221,7 @@ def main():
         result["single_cell_ms_per_fit"] = 1e3 * (time.perf_counter() - t1) / 10
         result["kernel_build_hbm"] = {"GBps": kmat_bytes / (ms[0] * 1e-3) / 1e9, "frac_of_8TBps": kmat_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not args.batched_only:
         extra = {}
         # F2: objective + gradient
         grad = np.zeros(3)

@@ -517,8 +517,9 @@ __global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict_
 struct PotrfProfile {
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  std::vector<std::pair<size_t, double>> gemm_marks;   // bulk updates (HEAD / TAIL): (index of start event, algorithmic flops)
-  std::vector<std::pair<size_t, double>> strip_marks;  // K = 64 strip updates inside an outer block
+  std::vector<std::pair<size_t, double>> gemm_marks;   // launches of the main GEMM kernel (bulk HEAD / TAIL updates and in-block updates with K > 128):
+                                                       // (index of start event, algorithmic flops)
+  std::vector<std::pair<size_t, double>> strip_marks;  // short-K in-block updates (K = 64: syrk_k64_kernel, K = 128: GEMM with C prefetch)
   std::vector<size_t> panel_marks;
   hipEvent_t next() {
     if (used == pool.size()) {
@@ -666,7 +667,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     const int rows = total_rows - c1;
     const double* L21 = A + (int64_t)c1 * lda + c0;
     double* A22 = A + (int64_t)c1 * lda + c1;
-    mark_gemm(st, n, rows - n, n, k, true);
+    mark_gemm(st, n, rows - n, n, k, k <= 128);  // K <= 128 runs the short-K kernels (syrk_k64 / C-prefetch GEMM), longer K the main GEMM kernel
     hipError_t e = (k == NB) ? launch_syrk_k64(st, rows, n, L21, lda, A22, lda, batch, cs)
                              : launch_gemm(st, 0, 1, rows, n, k, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64, batch, cs, cs, cs);
     mark_end(st);

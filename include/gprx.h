@@ -127,11 +127,12 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
 int gprx_last_timings(gprx_handle h, double* ms4);
 
 /* Per-launch timing of the Cholesky's two kernels (exact path), for bench.py's roofline line.
- * With profiling enabled every gprx_factorize / gprx_objective brackets each launch with HIP events
- * on the handle's stream (this perturbs the run slightly: keep it off inside timed regions).
- * gprx_last_profile: out8 = [bulk trailing-update GEMM (gemm_f64_kernel<0,1,..>) total ms, launches,
- *                           algorithmic flops, panel kernel total ms, launches, K=64 strip kernel total ms,
- *                           launches, algorithmic flops] of the last exact factorisation. */
+ * With profiling enabled every gprx_factorize / gprx_objective / gprx_factorize_batch brackets each launch with HIP
+ * events on the launch stream (this perturbs the run slightly: keep it off inside timed regions).
+ * gprx_last_profile: out8 = [main GEMM kernel gemm_f64_kernel<0,1,64,64,0> (bulk trailing updates and in-block updates
+ *                           with K > 128) total ms, launches, algorithmic flops (all cells of a batch), panel kernel
+ *                           total ms, launches, short-K in-block updates (K = 64 syrk_k64_kernel, K = 128 GEMM with C
+ *                           prefetch) total ms, launches, algorithmic flops] of the last exact factorisation(s). */
 int gprx_set_profiling(gprx_handle h, int enabled);
 int gprx_last_profile(gprx_handle h, double* out8);
 
