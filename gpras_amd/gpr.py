@@ -131,6 +131,9 @@ class GPRAS:
     def predict(self, x: NDArray[Any]) -> tuple[NDArray[Any], NDArray[Any]]:
         """Predictive mean and observation variance, each (n_samples, n_outputs) (gpr.py:322-342)."""
         x = x.astype(np.float64)
+        batched = self._predict_batched(x)
+        if batched is not None:
+            return batched
         means = []
         variances = []
         for model in self.models:
@@ -138,6 +141,32 @@ class GPRAS:
             means.append(pred[0])
             variances.append(pred[1])
         return np.concatenate(means, axis=1), np.concatenate(variances, axis=1)
+
+    def _predict_batched(self, x: NDArray[Any]):
+        """Exact models: the factorisations that ``predict_y`` recomputes per mode (gpr.py:337) are independent,
+        so all modes of an engine are factorised by one batched launch sequence (``Engine.factorize_batch``) and
+        each mode then predicts from its slot.  Same numbers as the per-mode loop (bit-identical factorisations)."""
+        if not self.models or any(m.Z is not None for m in self.models):
+            return None
+        if not all(hasattr(m.backend, "factorize_batch") for m in self.models):
+            return None
+        means = np.empty((x.shape[0], len(self.models)))
+        variances = np.empty((x.shape[0], len(self.models)))
+        by_engine: dict[int, list[int]] = {}
+        for i, m in enumerate(self.models):
+            by_engine.setdefault(id(m.backend), []).append(i)
+        for idx in by_engine.values():
+            eng = self.models[idx[0]].backend
+            units = [self.models[i].unit for i in idx]
+            thetas = np.stack([self.models[i].theta() for i in idx])
+            _, ok = eng.factorize_batch(units, thetas, 0)
+            if not ok.all():
+                bad = [idx[k] for k in np.flatnonzero(~ok)]
+                raise RuntimeError(f"kernel matrix not positive definite for mode(s) {bad}")
+            for slot, i in enumerate(idx):
+                eng.select_slot(slot)
+                means[:, i], variances[:, i] = eng.predict(x, include_noise=True)
+        return means, variances
 
     def to_file(self, json_path: str | Path, model_dir: str | Path | None = None) -> None:
         """Serialize the trained model (gpr.py:344-366).

@@ -168,6 +168,27 @@ class GPModel:
         loss, _ = self.backend.objective(self.unit, self.theta(), self.Z, self.mask, want_grad=False)
         return loss
 
+    def training_loss_many(self, variances, lengthscales, noises, chunk: int = 64):
+        """``training_loss`` of this unit at many hyperparameter settings (constrained values, isotropic lengthscale
+        or one row of lengthscales per candidate), evaluated by batched launch sequences of up to ``chunk`` cells.
+        Candidates whose kernel matrix is not positive definite get ``+inf``.  The model's own parameters are untouched."""
+        variances = np.atleast_1d(np.asarray(variances, dtype=np.float64))
+        count = variances.size
+        ls = np.asarray(lengthscales, dtype=np.float64)
+        ls = np.broadcast_to(ls.reshape(count, -1), (count, self.backend.n_len))
+        noises = np.broadcast_to(np.asarray(noises, dtype=np.float64), (count,))
+        thetas = np.empty((count, self.backend.n_theta))
+        thetas[:, 0] = softplus_inv(variances)
+        thetas[:, 1:-1] = softplus_inv(ls)
+        thetas[:, -1] = softplus_inv(noises - NOISE_LOWER)
+        out = np.empty(count)
+        for lo in range(0, count, chunk):
+            hi = min(count, lo + chunk)
+            losses, ok = self.backend.factorize_batch(np.full(hi - lo, self.unit, dtype=np.int32), thetas[lo:hi], self.mask)
+            out[lo:hi] = np.where(ok, losses, np.inf)
+        self.n_evals += count
+        return out
+
     def predict_y(self, xs):
         """Mean and observation variance (``SGPR.predict_y``, gpr.py:337), each of shape (N*, 1)."""
         self.backend.objective(self.unit, self.theta(), self.Z, self.mask, want_grad=False)

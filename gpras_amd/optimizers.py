@@ -25,6 +25,8 @@ def _optimize_adam(model, max_iter: int) -> None:
     """Keras ``Adam()`` defaults on the trainable variables, fresh state per call (gpr.py:147-173)."""
     lr, beta1, beta2, eps = 1e-3, 0.9, 0.999, 1e-7
     x = model.get_vector()
+    if x.size == 0:  # nothing trainable (e.g. the Z-only stage of an exact model): no step can change anything
+        return
     m = np.zeros_like(x)
     v = np.zeros_like(x)
     best = np.inf
@@ -123,11 +125,16 @@ def _optimize_multi_start(model, n_starts: int = 40, iter_initial: int = 20, ite
     _optimize_bfgs(model, iter_final)
 
 
-def _optimize_differential_evolutions(model, popsize: int = 15, max_iter: int = 500, seed=None, adam_iter: int = 3000, verbose=True) -> Any:
+def _optimize_differential_evolutions(
+    model, popsize: int = 15, max_iter: int = 500, seed=None, adam_iter: int = 3000, verbose=True, batched: bool = False
+) -> Any:
     """Adam on Z, then scipy differential evolution over log10 of the three hyperparameters (gpr.py:44-70).
 
     Every hyperparameter is frozen while DE runs, so the objective is ``-ELBO`` without priors.
-    ``seed``, ``adam_iter`` and ``verbose`` are additions (the reference prints every objective value).
+    ``seed``, ``adam_iter``, ``verbose`` and ``batched`` are additions (the reference prints every objective value).
+    ``batched=True`` (exact models): scipy evaluates a whole generation at once (``vectorized=True``, which implies
+    ``updating="deferred"`` -- a different, equally valid DE variant than the reference's immediate updating) and the
+    ``popsize * 3`` candidates are factorised by one batched launch sequence on the GPU.
     """
     model.set_all_trainable(False)
     model.set_trainable(Z=True)
@@ -141,7 +148,21 @@ def _optimize_differential_evolutions(model, popsize: int = 15, max_iter: int = 
             print(value)
         return model.training_loss()
 
-    result = differential_evolution(objective, param_bounds, popsize=popsize, maxiter=max_iter, seed=seed)
+    if batched:
+        if model.Z is not None or not hasattr(model.backend, "factorize_batch"):
+            raise ValueError("batched differential evolution needs an exact model on the HIP engine")
+
+        def objective_many(params):  # (3, S) -> (S,)
+            values = model.training_loss_many(10.0 ** params[0], 10.0 ** params[1], 10.0 ** params[2])
+            if verbose:
+                print(values)
+            return values
+
+        result = differential_evolution(
+            objective_many, param_bounds, popsize=popsize, maxiter=max_iter, seed=seed, vectorized=True, updating="deferred", polish=False
+        )
+    else:
+        result = differential_evolution(objective, param_bounds, popsize=popsize, maxiter=max_iter, seed=seed)
     model.assign(variance=10 ** result.x[0], lengthscales=10 ** result.x[1], noise=10 ** result.x[2])
     return result
 

@@ -99,3 +99,46 @@ def test_concurrent_workers_give_identical_models():
     m4, v4 = g4.predict(xs)
     assert np.array_equal(m1, m4) and np.array_equal(v1, v4)
     print(f"serial {t1:.3f} s, 4 workers {t4:.3f} s")
+
+
+def test_exact_predict_is_batched_and_equals_the_per_mode_loop():
+    """GPRAS.predict on exact models factorises all modes by one batched launch sequence; the numbers must equal
+    the reference-shaped loop (model.predict_y per mode) exactly, and the oracle to 1e-8."""
+    x, y, xs = make_regression(600, 5, n_outputs=4, n_test=70, config=9, unit=2)
+    g = GPRAS("Matern32")
+    g.fit(x, y, None, optimization_method="adam", max_iter=3)
+    for i, m in enumerate(g.models):  # distinct hyperparameters per mode
+        m.assign(variance=0.8 + 0.2 * i, lengthscales=0.7 + 0.1 * i, noise=0.05 * (i + 1))
+    mean, var = g.predict(xs)
+    loop = [m.predict_y(xs) for m in g.models]
+    assert np.array_equal(mean, np.concatenate([p[0] for p in loop], axis=1))
+    assert np.array_equal(var, np.concatenate([p[1] for p in loop], axis=1))
+    from oracle import exact as oex
+
+    for i, m in enumerate(g.models):
+        rm, rv = oex.predict("Matern32", x, y[:, i], m.variance, m.lengthscales, m.noise, xs)
+        assert np.max(np.abs(mean[:, i] - rm)) <= 1e-8 * np.max(np.abs(rm))
+        assert np.max(np.abs(var[:, i] - rv) / rv) <= 1e-8
+
+
+def test_batched_differential_evolution_on_exact_model():
+    """``batched=True``: scipy hands a whole generation to the objective, which the engine evaluates in one batched
+    launch sequence.  The objective values must equal single evaluations, and the search must not end above its start."""
+    x, y, _ = make_regression(300, 3, n_outputs=1, n_test=0, config=5, unit=4)
+    g = GPRAS("RBF")
+    g._init_models(x.astype(np.float64), y.astype(np.float64), None)
+    model = g.models[0]
+    model.set_all_trainable(False)
+    start = model.training_loss()
+    rng = np.random.default_rng(0)
+    cand = np.stack([rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 7), rng.uniform(-3, 0, 7)])
+    many = model.training_loss_many(10.0 ** cand[0], 10.0 ** cand[1], 10.0 ** cand[2])
+    for k in range(7):
+        model.assign(variance=10.0 ** cand[0, k], lengthscales=10.0 ** cand[1, k], noise=10.0 ** cand[2, k])
+        assert model.training_loss() == many[k]
+    g2 = GPRAS("RBF")
+    g2.fit(x, y, None, optimization_method="diffential_evolution", popsize=5, max_iter=4, seed=1, adam_iter=2, verbose=False, batched=True)
+    m2 = g2.models[0]
+    m2.set_all_trainable(False)
+    assert m2.training_loss() <= start
+    assert 0.1 <= m2.variance <= 10.0 and 0.1 <= m2.lengthscales <= 10.0 and 1e-3 <= m2.noise <= 1.0
