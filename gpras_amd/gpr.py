@@ -142,19 +142,21 @@ class GPRAS:
             variances.append(pred[1])
         return np.concatenate(means, axis=1), np.concatenate(variances, axis=1)
 
-    def _predict_batched(self, x: NDArray[Any]):
+    def _predict_batched(self, x: NDArray[Any], indices: list[int] | None = None):
         """Exact models: the factorisations that ``predict_y`` recomputes per mode (gpr.py:337) are independent,
         so all modes of an engine are factorised by one batched launch sequence (``Engine.factorize_batch``) and
         each mode then predicts from its slot.  Same numbers as the per-mode loop (bit-identical factorisations)."""
-        if not self.models or any(m.Z is not None for m in self.models):
+        todo = list(range(len(self.models))) if indices is None else list(indices)
+        models = [self.models[i] for i in todo]
+        if not models or any(m.Z is not None for m in models):
             return None
-        if not all(hasattr(m.backend, "factorize_batch") for m in self.models):
+        if not all(hasattr(m.backend, "factorize_batch") for m in models):
             return None
-        means = np.empty((x.shape[0], len(self.models)))
-        variances = np.empty((x.shape[0], len(self.models)))
+        means = np.full((x.shape[0], len(self.models)), np.nan)  # columns outside `indices` stay NaN
+        variances = np.full((x.shape[0], len(self.models)), np.nan)
         by_engine: dict[int, list[int]] = {}
-        for i, m in enumerate(self.models):
-            by_engine.setdefault(id(m.backend), []).append(i)
+        for i in todo:
+            by_engine.setdefault(id(self.models[i].backend), []).append(i)
         for idx in by_engine.values():
             eng = self.models[idx[0]].backend
             units = [self.models[i].unit for i in idx]

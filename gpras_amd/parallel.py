@@ -106,7 +106,11 @@ class ShardedGPRAS(GPRAS):
         mine = shard_units(k, self.rank, self.world)
         n_max = (k + self.world - 1) // self.world
         local = np.zeros((2, n_max, x.shape[0]))
+        batched = self._predict_batched(x, mine) if mine else None  # exact models: one batched launch sequence
         for row, u in enumerate(mine):
+            if batched is not None:
+                local[0, row], local[1, row] = batched[0][:, u], batched[1][:, u]
+                continue
             mean, var = self.models[u].predict_y(x)
             local[0, row] = mean[:, 0]
             local[1, row] = var[:, 0]
