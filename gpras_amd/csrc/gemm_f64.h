@@ -145,8 +145,24 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (PF ? 3 : 4)) voi
       tj = rest % tn;
     }
   } else {
-    ti = bid / p.tiles_n;
-    tj = bid % p.tiles_n;
+    const int tri = p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER);
+    if (tri == GEMM_B_UPPER || tri == GEMM_B_LOWER) {
+      // one triangular operand: the K range of a tile grows (UPPER) or shrinks (LOWER) with tj.  Longest tiles
+      // first (column-major over the tiles, longest column first): the launch ends with the short tiles instead
+      // of a tail of full-K tiles, and the 8 consecutive workgroups that the dispatcher deals to the 8 XCDs all
+      // have the same cost (row-major order with tiles_n a multiple of 8 gave XCD 7 54 % more work than XCD 0).
+      const int cj = bid / p.tiles_m;
+      ti = bid % p.tiles_m;
+      tj = (tri == GEMM_B_UPPER) ? p.tiles_n - 1 - cj : cj;
+    } else if (tri == GEMM_A_LOWER || tri == GEMM_A_UPPER) {
+      const int ri = bid / p.tiles_n;
+      tj = bid % p.tiles_n;
+      ti = (tri == GEMM_A_LOWER) ? p.tiles_m - 1 - ri : ri;
+    } else {
+      ti = bid / p.tiles_n;
+      tj = bid % p.tiles_n;
+      if (tri & (GEMM_B_LOWER | GEMM_B_UPPER)) tj = (tj + ti) % p.tiles_n;  // keep the XCDs balanced (see above)
+    }
   }
   const int m0 = ti * BM, n0 = tj * BN;
 

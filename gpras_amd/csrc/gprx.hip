@@ -1074,9 +1074,28 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
     HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
     h->have_linv = true;
   }
+  const double base = h->variance + (include_noise ? h->noise : 0.0);
+  if (use_inverse) {
+    // transposed formulation, test points along the rows: Kst = k(Xs, X) (ts x np), mean = Kst alpha (row dots),
+    // Vt = Kst L^-T as an NT GEMM -- both operands k-contiguous, the GEMM kernel's fastest case; op(B) = L^-T is
+    // upper triangular, so the K range of a tile ends at its last column and every tile row mixes short and long
+    // tiles (no tail of long tiles) -- and var = base - row sums of Vt^2.
+    for (int64_t t0 = 0; t0 < ns; t0 += tile) {
+      const int ts = (int)std::min<int64_t>(tile, ns - t0);
+      const int tsp = (int)round_up(ts, NB);
+      KmatArgs ka{xs_dev + t0 * h->d, h->X.p, h->invls.p, h->Ks.p, ld, ts, (int)h->n, h->d, tsp, np, h->variance, 0.0, 0, 0.0, nullptr, 0};
+      HIPCHK(h, launch_kmat(st, h->kid, ka));
+      hipLaunchKernelGGL(rowreduce_kernel, dim3((ts + 3) / 4), dim3(256), 0, st, (const double*)h->Ks.p, ld, (const double*)h->alpha.p, ts, np, 0.0,
+                         1.0, mean_dev + t0);
+      HIPCHK(h, launch_gemm(st, 0, 1, tsp, np, np, 1.0, h->Ks.p, ld, h->Xinv.p, ld, 0.0, Vbuf, ld, GEMM_B_UPPER, 128));
+      hipLaunchKernelGGL(rowreduce_kernel, dim3((ts + 3) / 4), dim3(256), 0, st, (const double*)Vbuf, ld, (const double*)nullptr, ts, np, base, -1.0,
+                         var_dev + t0);
+    }
+    HIPCHK(h, hipGetLastError());
+    return GPRX_OK;
+  }
   const int nchunks = (np + rows_per_chunk - 1) / rows_per_chunk;
   if ((rc = ensure(h, h->pred, sizeof(double) * (size_t)nchunks * tile))) return rc;
-  const double base = h->variance + (include_noise ? h->noise : 0.0);
   for (int64_t t0 = 0; t0 < ns; t0 += tile) {
     const int ts = (int)std::min<int64_t>(tile, ns - t0);
     const int tsp = (int)round_up(ts, NB);
@@ -1085,12 +1104,8 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
     dim3 grid((ts + 255) / 256, nchunks);
     hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, h->alpha.p, np, ts, rows_per_chunk, h->pred.p);
     hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, 0, mean_dev + t0);
-    if (use_inverse) {
-      HIPCHK(h, launch_gemm(st, 0, 0, np, tsp, np, 1.0, h->Xinv.p, ld, h->Ks.p, tile, 0.0, Vbuf, tile, GEMM_A_LOWER, 128));
-    } else {
-      HIPCHK(h, trsm_lower_left(st, h->Kmat.p, ld, h->invD.p, h->Ks.p, tile, np, tsp));
-    }
-    hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, (const double*)Vbuf, (int64_t)tile, (const double*)nullptr, np, ts, rows_per_chunk,
+    HIPCHK(h, trsm_lower_left(st, h->Kmat.p, ld, h->invD.p, h->Ks.p, tile, np, tsp));
+    hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, (const double*)h->Ks.p, (int64_t)tile, (const double*)nullptr, np, ts, rows_per_chunk,
                        h->pred.p);
     hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, base, -1.0, 0, var_dev + t0);
   }

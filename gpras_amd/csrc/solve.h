@@ -257,4 +257,31 @@ __global__ __launch_bounds__(256) void colreduce_final(const double* __restrict_
   out[t] = (accumulate ? out[t] : base) + scale * s;
 }
 
+// out[row] = base + scale * sum_c (w ? w[c] * M[row, c] : M[row, c]^2): one wave per row, 16-byte loads along the row
+// (ncols a multiple of 2, rows 16-byte aligned).  Used by the transposed predict (rows = test points).
+__global__ __launch_bounds__(256) void rowreduce_kernel(const double* __restrict__ M, int64_t ldm, const double* __restrict__ w, int nrows,
+                                                        int ncols, double base, double scale, double* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int lane = threadIdx.x & 63;
+  const double* mp = M + (int64_t)row * ldm;
+  double s0 = 0.0, s1 = 0.0;
+  if (w) {
+    for (int c = 2 * lane; c < ncols; c += 128) {
+      const d2 v = *reinterpret_cast<const d2*>(mp + c);
+      const d2 ww = *reinterpret_cast<const d2*>(w + c);
+      s0 = __builtin_fma(v.x, ww.x, s0);
+      s1 = __builtin_fma(v.y, ww.y, s1);
+    }
+  } else {
+    for (int c = 2 * lane; c < ncols; c += 128) {
+      const d2 v = *reinterpret_cast<const d2*>(mp + c);
+      s0 = __builtin_fma(v.x, v.x, s0);
+      s1 = __builtin_fma(v.y, v.y, s1);
+    }
+  }
+  const double s = wave_sum(s0 + s1);
+  if (lane == 0) out[row] = base + scale * s;
+}
+
 }  // namespace gprx
