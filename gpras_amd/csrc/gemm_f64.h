@@ -36,6 +36,8 @@ struct GemmArgs {
   int64_t strideA, strideB, strideC;  // element strides between batch entries (blockIdx.y)
   int ksplit;                          // > 0: blockIdx.z takes K slice [z * ksplit, (z+1) * ksplit) and writes slab z of C
   int64_t slab;                        // elements per slab
+  int inner = 0;                       // > 0: blockIdx.y = cell * inner + entry; cells are cellA / cellB / cellC elements apart
+  int64_t cellA = 0, cellB = 0, cellC = 0;
 };
 
 constexpr int GEMM_BK = 16;
@@ -120,9 +122,19 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (PF ? 3 : 4)) voi
   // each XCD a contiguous run of tiles: neighbours share operand panels in that XCD's L2), then, for
   // C_LOWER, decode the linear index over the lower trapezoid only -- every launched workgroup has
   // work, and the tiles are spread evenly over the XCDs.
-  p.A += (int64_t)blockIdx.y * p.strideA;
-  p.B += (int64_t)blockIdx.y * p.strideB;
-  p.C += (int64_t)blockIdx.y * p.strideC;
+  {
+    int entry = blockIdx.y;
+    if (p.inner > 0) {
+      const int cell = entry / p.inner;
+      entry -= cell * p.inner;
+      p.A += (int64_t)cell * p.cellA;
+      p.B += (int64_t)cell * p.cellB;
+      p.C += (int64_t)cell * p.cellC;
+    }
+    p.A += (int64_t)entry * p.strideA;
+    p.B += (int64_t)entry * p.strideB;
+    p.C += (int64_t)entry * p.strideC;
+  }
   int bid = blockIdx.x;
   if (!(p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER))) {
     // (with triangular operands the K range, i.e. the cost, varies along the tile order: keep the
@@ -442,9 +454,17 @@ inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A,
 // tile: 0 = choose, 128 or 64 (square workgroup tiles)
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0, int batch = 1,
-                              int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0) {
+                              int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0, int cells = 1, int64_t cellA = 0,
+                              int64_t cellB = 0, int64_t cellC = 0) {
   GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC, 0, 0};
-  if (M <= 0 || N <= 0 || batch <= 0) return hipSuccess;
+  if (M <= 0 || N <= 0 || batch <= 0 || cells <= 0) return hipSuccess;
+  if (cells > 1) {  // two-level batch: `batch` entries per cell
+    p.inner = batch;
+    p.cellA = cellA;
+    p.cellB = cellB;
+    p.cellC = cellC;
+    batch *= cells;
+  }
   if (tile == 0) {
     // 128 x 128 tiles (2 workgroups per CU) once they fill the chip more than twice over; otherwise
     // 64 x 64 tiles (4 per CU), which keep the tail short on the small updates of a factorisation

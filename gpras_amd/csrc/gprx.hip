@@ -75,7 +75,7 @@ struct gprx_ctx {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // batched exact factorisations (gprx_factorize_batch): `arena_slots` cell blocks, `cell_stride` doubles apart, each
   // [K (np + 64) x np | invD np x 64 | staged diagonal blocks np x 128 | alpha np]; parameter / result tables, one row per cell
-  Buf arena, cellpar, cellres;
+  Buf arena, cellpar, cellres, garena, gpartial;  // garena: per cell [L^-1 | K^-1] for batched gradients
   double* bpin = nullptr;  // pinned: [slots][CELL_PAR] parameters up, then [slots][CELL_RES] results down
   int arena_slots = 0;
   int64_t cell_stride = 0, off_invd = 0, off_stage = 0, off_alpha = 0;
@@ -518,6 +518,56 @@ int select_slot(gprx_handle h, int slot) {
   return GPRX_OK;
 }
 
+// Gradients of the LML for every cell of the batch just factorised (slots 0 .. count-1): the single-cell stages
+// (L^-1 by bottom-up doubling, K^-1 = L^-T L^-1 on the lower tiles, one trace pass for all 2 + d derivatives) with
+// the cell index in the grid.  g: count x ntheta, constrained parameters (variance, lengthscales, noise); rows of
+// failed cells are left untouched.
+int exact_gradient_batch(gprx_handle h, int count, double* g) {
+  const int np = (int)h->np;
+  const int64_t ld = h->np, cs = h->cell_stride, gs = 2 * (int64_t)h->np * h->np;
+  int rc;
+  if ((rc = ensure(h, h->garena, sizeof(double) * (size_t)gs * count))) return rc;
+  const int tiles = np / KM_T;
+  const int width = 2 + h->d;
+  const int64_t ps = (int64_t)tiles * tiles * width;  // partials per cell; the count x width sums follow all partials
+  if ((rc = ensure(h, h->gpartial, sizeof(double) * (size_t)(ps + width) * count))) return rc;
+  hipStream_t st = h->stream;
+  double* X0 = h->garena.p;
+  double* T0 = h->garena.p + (int64_t)np * ld;
+  double* K0 = h->arena.p;
+  for (int c = 0; c < count; ++c) HIPCHK(h, hipMemsetAsync(X0 + (int64_t)c * gs, 0, sizeof(double) * h->np * ld, st));
+  HIPCHK(h, trtri_lower(st, K0, ld, K0 + h->off_invd, X0, ld, T0, ld, np, count, cs, gs));
+  HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER,
+                        potrf_tuning().update_tile, count, gs, gs, gs));
+  TraceArgs ta{h->X.p, h->X.p, nullptr, T0, ld, K0 + h->off_alpha, K0 + h->off_alpha, -1.0, 1.0, (int)h->n, (int)h->n, h->d, 0.0, 1, h->gpartial.p,
+               nullptr, 0, tiles};
+  ta.cell_par = h->cellpar.p;
+  ta.w_stride = gs;
+  ta.uv_stride = cs;
+  ta.partial_stride = ps;
+  HIPCHK(h, launch_trace(st, h->kid, ta, tiles * tiles, count));
+  double* sums0 = h->gpartial.p + ps * count;
+  hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)h->gpartial.p, tiles * tiles, width, sums0, ps);
+  std::vector<double> host((size_t)width * count);
+  HIPCHK(h, hipMemcpyAsync(host.data(), sums0, sizeof(double) * width * count, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  for (int c = 0; c < count; ++c) {
+    if (!h->slot_ok[c]) continue;
+    const double* hs = host.data() + (size_t)c * width;
+    double* gc = g + (size_t)c * h->ntheta;
+    gc[0] = 0.5 * hs[0];
+    if (h->ard) {
+      for (int k = 0; k < h->d; ++k) gc[1 + k] = 0.5 * hs[2 + k];
+    } else {
+      double sum = 0.0;
+      for (int k = 0; k < h->d; ++k) sum += hs[2 + k];
+      gc[1] = 0.5 * sum;
+    }
+    gc[1 + h->nlen] = 0.5 * hs[1];
+  }
+  return GPRX_OK;
+}
+
 // gradient of the LML w.r.t. constrained (variance, lengthscales[nlen], noise) -> g[0 .. nlen+1]
 int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   const int np = (int)h->np;
@@ -805,7 +855,7 @@ int gprx_destroy(gprx_handle h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
                  &h->pred, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs, &h->dZ,
-                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres})
+                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial})
     if (b->p && !b->borrowed) hipFree(b->p);
   if (h->bpin) hipHostFree(h->bpin);
   for (auto& ev : h->bev)
@@ -866,6 +916,14 @@ int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units) 
   return GPRX_OK;
 }
 
+// priors and softplus chain rule on the hyperparameter part of a gradient; loss = -(value + log prior)
+void chain_rule(gprx_handle h, const Theta& t, int mask, const double* g, double* grad) {
+  grad[0] = (mask & GPRX_TRAIN_VARIANCE) ? -(g[0] + ln_dlogpdf(t.variance)) * sigmoid(t.w_var) : 0.0;
+  for (int k = 0; k < h->nlen; ++k)
+    grad[1 + k] = (mask & GPRX_TRAIN_LENGTHSCALE) ? -(g[1 + k] + ln_dlogpdf(t.ls[k])) * sigmoid(t.w_len[k]) : 0.0;
+  grad[1 + h->nlen] = (mask & GPRX_TRAIN_NOISE) ? -(g[1 + h->nlen] + ln_dlogpdf(t.noise)) * sigmoid(t.w_noise) : 0.0;
+}
+
 static int objective_impl(gprx_handle h, int unit, const double* theta, const double* z, int mask, double* loss, double* grad) {
   int rc;
   if ((rc = check_handle(h))) return rc;
@@ -892,11 +950,7 @@ static int objective_impl(gprx_handle h, int unit, const double* theta, const do
       if ((rc = exact_gradient(h, t, g.data()))) return rc;
     }
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
-    // priors and softplus chain rule; loss = -(value + log prior)
-    grad[0] = (mask & GPRX_TRAIN_VARIANCE) ? -(g[0] + ln_dlogpdf(t.variance)) * sigmoid(t.w_var) : 0.0;
-    for (int k = 0; k < h->nlen; ++k)
-      grad[1 + k] = (mask & GPRX_TRAIN_LENGTHSCALE) ? -(g[1 + k] + ln_dlogpdf(t.ls[k])) * sigmoid(t.w_len[k]) : 0.0;
-    grad[1 + h->nlen] = (mask & GPRX_TRAIN_NOISE) ? -(g[1 + h->nlen] + ln_dlogpdf(t.noise)) * sigmoid(t.w_noise) : 0.0;
+    chain_rule(h, t, mask, g.data(), grad);
     if (sparse) {
       const int64_t nz = h->m * h->d;
       if (mask & GPRX_TRAIN_Z) {
@@ -1011,6 +1065,33 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
   if ((rc = check_handle(h))) return rc;
   if (count < 0 || !units || !theta || !losses) return fail(h, GPRX_EINVAL, "null argument");
   const int64_t gw = h->ntheta + h->m * h->d;
+  if (h->m == 0 && count > 1 && h->d <= CELL_PAR - CELL_PAR_LS) {
+    // exact models: every stage once for all cells (batched launches), results identical to the loop below
+    std::vector<Theta> ts(count);
+    for (int i = 0; i < count; ++i) {
+      if (units[i] < 0 || units[i] >= h->n_units) return fail(h, GPRX_EINVAL, "unit out of range (call gprx_set_data first)");
+      for (int k = 0; k < h->ntheta; ++k)
+        if (!std::isfinite(theta[(int64_t)i * h->ntheta + k])) return fail(h, GPRX_EINVAL, "theta is not finite");
+      ts[i] = decode_theta(h, theta + (int64_t)i * h->ntheta);
+    }
+    std::vector<double> lml(count);
+    const int frc = exact_factorize_batch(h, count, units, ts.data(), lml.data(), nullptr);
+    if (frc != GPRX_OK && frc != GPRX_ENOTPD) return frc;
+    for (int i = 0; i < count; ++i) losses[i] = -(lml[i] + log_prior(h, ts[i], mask));
+    if (grads) {
+      std::vector<double> g((size_t)count * h->ntheta, 0.0);
+      if ((rc = exact_gradient_batch(h, count, g.data()))) return rc;
+      for (int i = 0; i < count; ++i) {
+        double* gi = grads + (int64_t)i * gw;
+        if (h->slot_ok[i]) {
+          chain_rule(h, ts[i], mask, g.data() + (size_t)i * h->ntheta, gi);
+        } else {
+          for (int k = 0; k < h->ntheta; ++k) gi[k] = std::numeric_limits<double>::quiet_NaN();
+        }
+      }
+    }
+    return frc;
+  }
   for (int i = 0; i < count; ++i) {
     rc = objective_impl(h, units[i], theta + (int64_t)i * h->ntheta, z ? z + (int64_t)i * h->m * h->d : nullptr, mask, losses + i,
                         grads ? grads + (int64_t)i * gw : nullptr);

@@ -30,6 +30,10 @@ struct TraceArgs {
   double* wh_out;        // optional (n1, n2) store of w * variance * h (feeds the dZ GEMM), leading dimension ldwh
   int64_t ldwh;
   int tiles_n;
+  // batched (blockIdx.y = cell): lengthscales and variance from row `cell` of the cell-parameter table (kmat.h), W / u, v /
+  // partial advanced by their per-cell strides
+  const double* cell_par = nullptr;
+  int64_t w_stride = 0, uv_stride = 0, partial_stride = 0;
 };
 
 // One workgroup per 64 x 64 tile.  Thread mapping as kmat_kernel: 8 rows x 2 columns per thread.
@@ -40,6 +44,17 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
   __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
   __shared__ double sRed[4][KM_DC + 2];
+  if (p.cell_par) {
+    const double* par = p.cell_par + (int64_t)blockIdx.y * CELL_PAR;
+    p.ls = par + CELL_PAR_LS;
+    p.variance = par[0];
+    p.W += (int64_t)blockIdx.y * p.w_stride;
+    if (p.u) {
+      p.u += (int64_t)blockIdx.y * p.uv_stride;
+      p.v += (int64_t)blockIdx.y * p.uv_stride;
+    }
+    p.partial += (int64_t)blockIdx.y * p.partial_stride;
+  }
   const int ti = blockIdx.x / p.tiles_n, tj = blockIdx.x % p.tiles_n;
   double* out = p.partial + (int64_t)blockIdx.x * (2 + p.d);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -181,16 +196,19 @@ __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, c
 }
 
 // out[e] = sum over workgroups of partial[wg][e]
-__global__ __launch_bounds__(64) void trace_final(const double* __restrict__ partial, int nwg, int width, double* __restrict__ out) {
+__global__ __launch_bounds__(64) void trace_final(const double* __restrict__ partial, int nwg, int width, double* __restrict__ out,
+                                                  int64_t partial_stride = 0) {
   const int e = blockIdx.x;
+  partial += (int64_t)blockIdx.y * partial_stride;  // batched: blockIdx.y = cell, results width apart
+  out += (int64_t)blockIdx.y * width;
   double s = 0.0;
   for (int w = threadIdx.x; w < nwg; w += 64) s += partial[(int64_t)w * width + e];
   s = wave_sum(s);
   if (threadIdx.x == 0) out[e] = s;
 }
 
-inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid) {
-  dim3 g(grid), b(256);
+inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid, int cells = 1) {
+  dim3 g(grid, cells), b(256);
   switch (kid) {
     case 0: hipLaunchKernelGGL(trace_kernel<0>, g, b, 0, st, p); break;
     case 1: hipLaunchKernelGGL(trace_kernel<1>, g, b, 0, st, p); break;

@@ -148,8 +148,11 @@ inline hipError_t trsm_lower_left_t(hipStream_t st, const double* L, int64_t lda
 }
 
 // ---- inverse of the Cholesky factor: X = L^-1 (lower), recursive, two GEMMs per node ------------
-__global__ __launch_bounds__(256) void scatter_inv_diag(const double* __restrict__ inv_diag, double* __restrict__ X, int64_t ldx) {
+__global__ __launch_bounds__(256) void scatter_inv_diag(const double* __restrict__ inv_diag, double* __restrict__ X, int64_t ldx,
+                                                        int64_t cs_in, int64_t cs_out) {
   const int blk = blockIdx.x;
+  inv_diag += (int64_t)blockIdx.y * cs_in;  // batched: blockIdx.y = cell
+  X += (int64_t)blockIdx.y * cs_out;
   const double* src = inv_diag + (int64_t)blk * NB * NB;
   double* dst = X + (int64_t)blk * NB * ldx + blk * NB;
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
@@ -161,9 +164,10 @@ __global__ __launch_bounds__(256) void scatter_inv_diag(const double* __restrict
 // Bottom-up doubling: at level s (64, 128, ...) adjacent diagonal blocks X11, X22 of size s are already
 // inverted; X21 = -X22 (L21 X11) for all pairs at once (batched GEMMs: two launches per level instead of
 // two per tree node).  A ragged last pair (n not a multiple of 2 s) gets its own launches.
+// cells > 1: the same inversion for `cells` factors; L and inv_diag are csL doubles apart, X and T csX doubles apart.
 inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* X, int64_t ldx, double* T,
-                              int64_t ldt, int np) {
-  hipLaunchKernelGGL(scatter_inv_diag, dim3(np / NB), dim3(256), 0, st, inv_diag, X, ldx);
+                              int64_t ldt, int np, int cells = 1, int64_t csL = 0, int64_t csX = 0) {
+  hipLaunchKernelGGL(scatter_inv_diag, dim3(np / NB, cells), dim3(256), 0, st, inv_diag, X, ldx, csL, csX);
   for (int s = NB; s < np; s *= 2) {
     const int full = np / (2 * s);            // pairs with two complete blocks
     const int rem = np - full * 2 * s;        // leftover columns/rows after the complete pairs
@@ -175,9 +179,11 @@ inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, cons
       double* X22 = X + (int64_t)(off + n1) * ldx + (off + n1);
       double* X21 = X + (int64_t)(off + n1) * ldx + off;
       double* T21 = T + (int64_t)(off + n1) * ldt + off;
-      hipError_t e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L21, lda, X11, ldx, 0.0, T21, ldt, GEMM_B_LOWER, 0, batch, sa, sx, stt);
+      hipError_t e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L21, lda, X11, ldx, 0.0, T21, ldt, GEMM_B_LOWER, 0, batch, sa, sx, stt, cells, csL,
+                                 csX, csX);
       if (e != hipSuccess) return e;
-      return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X22, ldx, T21, ldt, 0.0, X21, ldx, GEMM_A_LOWER, 0, batch, sx, stt, sx);
+      return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X22, ldx, T21, ldt, 0.0, X21, ldx, GEMM_A_LOWER, 0, batch, sx, stt, sx, cells, csX, csX,
+                         csX);
     };
     if (full > 0) {
       hipError_t e = level(0, s, s, full);

@@ -92,6 +92,22 @@ class Engine:
             check(rc, self._h)
         return losses, status == 0
 
+    def objective_batch(self, units, thetas, mask: int, want_grad: bool = True):
+        """Exact models: ``training_loss`` (and gradient w.r.t. theta) of ``len(units)`` cells by batched launches
+        (``gprx_objective_batch``).  Returns ``(losses, grads or None, ok)``; failed cells hold NaN."""
+        if self.m != 0:
+            raise ValueError("objective_batch is for exact models")
+        units = np.ascontiguousarray(units, dtype=np.int32)
+        thetas = as_f64(thetas)
+        if thetas.shape != (units.size, self.n_theta):
+            raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
+        losses = np.empty(units.size)
+        grads = np.zeros((units.size, self.n_theta)) if want_grad else None
+        rc = self._lib.gprx_objective_batch(self._h, units.size, ptr(units), ptr(thetas), None, mask, ptr(losses), ptr(grads) if want_grad else None)
+        if rc not in (_lib.GPRX_OK, _lib.GPRX_ENOTPD):
+            check(rc, self._h)
+        return losses, grads, np.isfinite(losses)
+
     def select_slot(self, slot: int):
         """Make slot ``slot`` of the last ``factorize_batch`` the current factorisation (for ``predict``)."""
         check(self._lib.gprx_select_slot(self._h, int(slot)), self._h)

@@ -198,3 +198,40 @@ def test_factorize_batch_reports_failed_cells(lib):
             assert rc == _lib.GPRX_OK
     finally:
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("kernel,n,d,ard,cells", [("RBF", 520, 4, False, 6), ("Matern52", 700, 6, True, 4), ("Exponential", 200, 3, True, 9)])
+def test_objective_batch_equals_single_calls(lib, kernel, n, d, ard, cells):
+    """Batched loss + gradient (every stage once for all cells) against gprx_objective per cell (bit-identical) and
+    against the oracle (1e-9 loss, 1e-7 gradient)."""
+    x, y, _ = make_regression(n, d, n_outputs=3, n_test=0, config=12, unit=n)
+    h = make_handle(lib, n, d, kernel, ard, x, y)
+    nt = 2 + (d if ard else 1)
+    try:
+        rng = np.random.default_rng(5)
+        units = np.ascontiguousarray(rng.integers(0, 3, size=cells), dtype=np.int32)
+        thetas = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, nt)))
+        losses = np.zeros(cells)
+        grads = np.zeros((cells, nt))
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, ALL, ptr(losses), ptr(grads)), h)
+        for c in range(cells):
+            th = np.ascontiguousarray(thetas[c])
+            single = C.c_double()
+            g1 = np.zeros(nt)
+            check(lib.gprx_objective(h, int(units[c]), ptr(th), None, ALL, C.byref(single), ptr(g1)), h)
+            assert single.value == losses[c]
+            assert np.array_equal(g1, grads[c])
+            wl = th[1:-1] if ard else float(th[1])
+            ref_loss, ref_g = oex.loss_and_grad(kernel, x, y[:, units[c]], float(th[0]), wl, float(th[-1]))
+            ref_grad = np.concatenate([[ref_g["variance"]], np.atleast_1d(ref_g["lengthscales"]), [ref_g["noise"]]])
+            assert abs(losses[c] - ref_loss) <= 1e-9 * abs(ref_loss)
+            assert np.max(np.abs(grads[c] - ref_grad)) <= 1e-7 * np.max(np.abs(ref_grad))
+        # loss only, partial mask
+        l2 = np.zeros(cells)
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, _lib.TRAIN_NOISE, ptr(l2), None), h)
+        for c in range(cells):
+            single = C.c_double()
+            check(lib.gprx_factorize(h, int(units[c]), ptr(np.ascontiguousarray(thetas[c])), None, _lib.TRAIN_NOISE, C.byref(single)), h)
+            assert single.value == l2[c]
+    finally:
+        lib.gprx_destroy(h)
