@@ -142,3 +142,22 @@ def test_batched_differential_evolution_on_exact_model():
     m2.set_all_trainable(False)
     assert m2.training_loss() <= start
     assert 0.1 <= m2.variance <= 10.0 and 0.1 <= m2.lengthscales <= 10.0 and 1e-3 <= m2.noise <= 1.0
+
+
+def test_lockstep_fit_on_the_engine_equals_the_serial_loop():
+    """Exact models, 5 modes, L-BFGS-B: the lock-step fit (batched evaluations) and the reference-shaped serial loop
+    must end at bit-identical parameters and predictions; the oracle's serial restatement agrees to optimiser accuracy."""
+    x, y, xs = make_regression(320, 4, n_outputs=5, n_test=40, config=10, unit=3)
+    a = GPRAS("Matern52")
+    a.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=8)
+    assert a.lockstep_stats["batches"] < a.lockstep_stats["evaluations"]
+    b = GPRAS("Matern52")
+    b.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=8, lockstep=False)
+    for ma, mb in zip(a.models, b.models):
+        assert ma.variance == mb.variance and ma.noise == mb.noise and np.array_equal(ma.lengthscales, mb.lengthscales)
+    pa, pb = a.predict(xs), b.predict(xs)
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+    ref = gpras_oracle.GPRASOracle("Matern52")
+    ref.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=8)
+    for ma, mr in zip(a.models, ref.models):
+        assert ma.training_loss() == pytest.approx(mr.training_loss(), rel=1e-6)

@@ -177,3 +177,62 @@ def test_file_round_trip_and_plumbing_config1(oracle_engine, tmp_path):
         pickle.dump({"kernel": "RBF"}, f)
     with pytest.raises(ValueError):
         gpr.GPRAS.from_file(tmp_path / "foreign.bin")
+
+
+class BatchedOracleBackend(OracleBackend):
+    """The stand-in with the batched entry point of the HIP engine (a loop here): exercises the lock-step driver."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.batch_sizes = []
+
+    def objective_batch(self, units, thetas, mask, want_grad=True):
+        self.batch_sizes.append(len(units))
+        out = [self.objective(u, t, None, mask, want_grad) for u, t in zip(units, thetas)]
+        losses = np.array([o[0] for o in out])
+        grads = np.stack([o[1] for o in out]) if want_grad else None
+        return losses, grads, np.isfinite(losses)
+
+
+@pytest.mark.parametrize("method,kwargs", [("L-BFGS-B", {"max_iter": 6}), ("adam", {"max_iter": 4}), ("two-stage", {"max_iter": 3})])
+def test_lockstep_fit_equals_serial_loop(monkeypatch, method, kwargs):
+    """K optimiser drivers in K threads, every round of evaluations as one batch: parameters bit-identical to the
+    serial per-mode loop, although the modes need different numbers of evaluations."""
+    x, y, _ = make_regression(60, 3, n_outputs=4, n_test=0, config=8, unit=0)
+    monkeypatch.setattr(gpr, "Engine", BatchedOracleBackend)
+    a = gpr.GPRAS("Matern32")
+    a.fit(x, y, None, optimization_method=method, **kwargs)
+    assert a.lockstep_stats["batches"] > 0 and max(a.engine.batch_sizes) == 4
+    assert a.lockstep_stats["evaluations"] == sum(m.n_evals for m in a.models)
+    b = gpr.GPRAS("Matern32")
+    b.fit(x, y, None, optimization_method=method, lockstep=False, **kwargs)
+    for ma, mb in zip(a.models, b.models):
+        assert ma.variance == mb.variance and ma.noise == mb.noise and np.array_equal(ma.lengthscales, mb.lengthscales)
+        assert ma.n_evals == mb.n_evals and ma.backend is a.engine
+
+
+def test_lockstep_propagates_failures_without_deadlock(monkeypatch):
+    class Failing(BatchedOracleBackend):
+        def objective(self, unit, theta, z, mask, want_grad=True):
+            if unit == 2:
+                raise np.linalg.LinAlgError("unit 2 fails")
+            return super().objective(unit, theta, z, mask, want_grad)
+
+        def objective_batch(self, units, thetas, mask, want_grad=True):
+            losses, grads = [], []
+            for u, t in zip(units, thetas):
+                if u == 2:
+                    losses.append(np.nan)
+                    grads.append(np.full(self.n_theta, np.nan))
+                else:
+                    lo, g = super().objective(u, t, None, mask, True)
+                    losses.append(lo)
+                    grads.append(g)
+            losses = np.array(losses)
+            return losses, (np.stack(grads) if want_grad else None), np.isfinite(losses)
+
+    x, y, _ = make_regression(40, 2, n_outputs=3, n_test=0, config=8, unit=1)
+    monkeypatch.setattr(gpr, "Engine", Failing)
+    g = gpr.GPRAS("RBF")
+    with pytest.raises(np.linalg.LinAlgError):
+        g.fit(x, y, None, optimization_method="adam", max_iter=3)
