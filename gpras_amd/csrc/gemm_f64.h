@@ -18,6 +18,8 @@
 // the j-th MFMA (the sum over k is order-free as long as A and B agree), so a KC image is read
 // with two ds_read_b128 per 16-row fragment.  C/D: col = l & 15, row = (l >> 4) + 4 * reg.
 #pragma once
+#include <cstdlib>
+
 #include "gprx_common.h"
 
 namespace gprx {
@@ -465,6 +467,8 @@ inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int 
     p.cellC = cellC;
     batch *= cells;
   }
+  static const int force_tile = getenv("GPRX_FORCE_TILE") ? atoi(getenv("GPRX_FORCE_TILE")) : 0;  // experiments
+  if (force_tile) tile = force_tile;
   if (tile == 0) {
     // 128 x 128 tiles (2 workgroups per CU) once they fill the chip more than twice over; otherwise
     // 64 x 64 tiles (4 per CU), which keep the tail short on the small updates of a factorisation

@@ -165,8 +165,9 @@ __global__ __launch_bounds__(256) void scatter_inv_diag(const double* __restrict
 // inverted; X21 = -X22 (L21 X11) for all pairs at once (batched GEMMs: two launches per level instead of
 // two per tree node).  A ragged last pair (n not a multiple of 2 s) gets its own launches.
 // cells > 1: the same inversion for `cells` factors; L and inv_diag are csL doubles apart, X and T csX doubles apart.
+// tile: GEMM tile (0 = launch_gemm's choice).
 inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* X, int64_t ldx, double* T,
-                              int64_t ldt, int np, int cells = 1, int64_t csL = 0, int64_t csX = 0) {
+                              int64_t ldt, int np, int cells = 1, int64_t csL = 0, int64_t csX = 0, int tile = 0) {
   hipLaunchKernelGGL(scatter_inv_diag, dim3(np / NB, cells), dim3(256), 0, st, inv_diag, X, ldx, csL, csX);
   for (int s = NB; s < np; s *= 2) {
     const int full = np / (2 * s);            // pairs with two complete blocks
@@ -179,10 +180,10 @@ inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, cons
       double* X22 = X + (int64_t)(off + n1) * ldx + (off + n1);
       double* X21 = X + (int64_t)(off + n1) * ldx + off;
       double* T21 = T + (int64_t)(off + n1) * ldt + off;
-      hipError_t e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L21, lda, X11, ldx, 0.0, T21, ldt, GEMM_B_LOWER, 0, batch, sa, sx, stt, cells, csL,
+      hipError_t e = launch_gemm(st, 0, 0, n2, n1, n1, 1.0, L21, lda, X11, ldx, 0.0, T21, ldt, GEMM_B_LOWER, tile, batch, sa, sx, stt, cells, csL,
                                  csX, csX);
       if (e != hipSuccess) return e;
-      return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X22, ldx, T21, ldt, 0.0, X21, ldx, GEMM_A_LOWER, 0, batch, sx, stt, sx, cells, csX, csX,
+      return launch_gemm(st, 0, 0, n2, n1, n2, -1.0, X22, ldx, T21, ldt, 0.0, X21, ldx, GEMM_A_LOWER, tile, batch, sx, stt, sx, cells, csX, csX,
                          csX);
     };
     if (full > 0) {
