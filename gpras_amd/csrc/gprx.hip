@@ -433,26 +433,48 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     for (int k = 0; k < h->d; ++k) row[CELL_PAR_LS + k] = ts[c].ls[k];
     h->slot_ok[c] = 0;
   }
-  const bool lookahead = !potrf_tuning().no_lookahead && getenv("GPRX_BATCH_LOOKAHEAD") != nullptr;
-  if (lookahead && (rc = ensure_lookahead(h))) return rc;
+  // Two groups of cells on two streams (from 32 cells on): the groups run the same launch sequence out of phase, so the
+  // latency-bound panel launches of one overlap the MFMA-bound updates of the other (measured at N = 4096: +2.5 % at 32
+  // cells, +3 % at 64, nothing at 16, -5 % at 8).
+  // Per-cell arithmetic is unchanged.  GPRX_BATCH_GROUPS=1 keeps one group; profiling needs a single stream.
+  static const int env_groups = getenv("GPRX_BATCH_GROUPS") ? atoi(getenv("GPRX_BATCH_GROUPS")) : 0;
+  const int groups = h->profiling ? 1 : (env_groups > 0 ? std::min(env_groups, 2) : (count >= 32 ? 2 : 1));
+  if (groups > 1 && (rc = ensure_lookahead(h))) return rc;
   HIPCHK(h, hipEventRecord(h->bev[0], st));
   HIPCHK(h, hipMemcpyAsync(h->cellpar.p, par, sizeof(double) * CELL_PAR * count, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemsetAsync(h->cellres.p, 0, sizeof(double) * CELL_RES * count, st));
-  double* K0 = h->arena.p;
-  KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
-  ka.cell_par = h->cellpar.p;
-  ka.out_stride = cs;
-  HIPCHK(h, launch_kmat(st, h->kid, ka, count));
-  hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, count), dim3(256), 0, st, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p,
-                     (const double*)h->cellpar.p, (int)h->n, np, NB, cs);
-  int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
   if (h->profiling) h->prof.reset();
-  HIPCHK(h, potrf_lower(st, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr,
-                        lookahead ? &h->pstreams : nullptr, count, cs, 2 * CELL_RES));
-  const double* beta = K0 + (int64_t)np * ld;
-  hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, count), dim3(256), 0, st, beta, K0 + h->off_alpha, np, cs);
-  hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)K0, ld, beta, np, h->cellres.p, cs, CELL_RES);
-  HIPCHK(h, trsv_lower(st, K0, ld, K0 + h->off_invd, K0 + h->off_alpha, np, true, count, cs));
+  auto enqueue_group = [&](hipStream_t gs, int c0, int cnt) -> int {
+    double* K0 = h->arena.p + (int64_t)c0 * cs;
+    const double* cpar = h->cellpar.p + (int64_t)c0 * CELL_PAR;
+    double* cres = h->cellres.p + (int64_t)c0 * CELL_RES;
+    KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
+    ka.cell_par = cpar;
+    ka.out_stride = cs;
+    HIPCHK(h, launch_kmat(gs, h->kid, ka, cnt));
+    hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
+                       (int)h->n, np, NB, cs);
+    int* info0 = reinterpret_cast<int*>(cres + 2);
+    HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
+                          2 * CELL_RES));
+    const double* beta = K0 + (int64_t)np * ld;
+    hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
+    hipLaunchKernelGGL(logdet_quad_kernel, dim3(cnt), dim3(256), 0, gs, (const double*)K0, ld, beta, np, cres, cs, CELL_RES);
+    HIPCHK(h, trsv_lower(gs, K0, ld, K0 + h->off_invd, K0 + h->off_alpha, np, true, cnt, cs));
+    return GPRX_OK;
+  };
+  if (groups == 1) {
+    if ((rc = enqueue_group(st, 0, count))) return rc;
+  } else {
+    const int first = (count + 1) / 2;
+    hipStream_t aux = h->pstreams.aux;
+    HIPCHK(h, hipEventRecord(h->pstreams.block_done, st));  // parameter table and cleared results are on the main stream
+    HIPCHK(h, hipStreamWaitEvent(aux, h->pstreams.block_done, 0));
+    if ((rc = enqueue_group(st, 0, first))) return rc;
+    if ((rc = enqueue_group(aux, first, count - first))) return rc;
+    HIPCHK(h, hipEventRecord(h->pstreams.tail_done, aux));
+    HIPCHK(h, hipStreamWaitEvent(st, h->pstreams.tail_done, 0));
+  }
   HIPCHK(h, hipMemcpyAsync(res, h->cellres.p, sizeof(double) * CELL_RES * count, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipEventRecord(h->bev[1], st));
   HIPCHK(h, hipStreamSynchronize(st));
