@@ -1334,6 +1334,7 @@ int gprx_set_tuning(const char* key, int value) {
   else if (k == "panel_rows" && (value == 0 || value == 128 || value == 256)) t.panel_rows = value;
   else if (k == "panel_occ" && (value == 0 || value == 2 || value == 3)) t.panel_occ = value;
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
+  else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
   else return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
   return GPRX_OK;
 }

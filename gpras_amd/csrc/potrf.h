@@ -50,6 +50,7 @@ struct PanelCtx {
   double* sX;     // [rows][9]  current sub-panel, solved (MFMA operands of the trailing update)
   double* out;    // this thread's output row (global memory or the diagonal-block staging area); nullptr: none
   double* inv_diag;
+  double* rinv_out;  // last workgroup: the 64 reciprocal pivots, stored behind the staged diagonal block
   int ident;      // >= 0: this thread carries identity row `ident` (last workgroup)
   int tid, wave, g, r;
   int zero_above;  // diagonal-block rows: entries right of the diagonal are zero
@@ -101,6 +102,10 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[RT][4], PanelCtx& c) {
       l[i][j] = t * ri;
     }
   }
+  if (c.rinv_out && c.tid == 0) {  // reciprocal pivots for potrf_rows_kernel (split panel): exactly the values used here
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.rinv_out[C0 + j] = rinv[j];
+  }
   if constexpr (P == 1) { PSTAMP(12) }
   if (c.tid < PWG_ROWS) {
     // own row: x = a[C0 .. C0+7] L_dd^-T
@@ -130,6 +135,15 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[RT][4], PanelCtx& c) {
   if constexpr (P == 1) { PSTAMP(13) }
   __syncthreads();
   if constexpr (P == 1) { PSTAMP(14) }
+  // the solved values return to the accumulators of the lanes that hold these columns: the panel leaves through
+  // one coalesced store pass at the end (16 lanes = one 128-byte line) instead of 16-byte stores scattered over 64
+  // rows per instruction -- 4096 write requests per workgroup that the L2 had to merge
+  if ((c.r >> 3) == HALF) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = c.sX[(WROWS * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)];
+  }
   // C: trailing columns [C0 + 8, 64) of this wave's rows: acc -= X_rows (32 x 8) * X_diag(16 kt .. +15, 8)^T
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
   c.zero_above = c.tid < NB ? c.tid : (1 << 30);
   c.bad = 0;
   const bool last = (int)blockIdx.x == nchunks;
+  c.rinv_out = last ? stage_out + NB * NB : nullptr;
   if (last) flush_staged_block(prev_stage, prev_dst, lda, prev_pw, c.tid);
   // where this thread's solved row goes (thread t < PWG_ROWS owns workgroup row t)
   c.out = nullptr;
@@ -220,12 +235,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
   if (c.tid < NB) {
     if (last) c.out = stage_out + c.tid * NB;  // the factored diagonal block is staged (in-place hazard, see above)
   } else if (c.tid < PWG_ROWS) {
-    if (!last) {
-      const int idx = blockIdx.x * PANEL_ROWS + (c.tid - NB);
-      if (idx < rows_below) c.out = A + (int64_t)(NB + idx) * lda;
-    } else if (c.tid < 2 * NB) {
-      c.ident = c.tid - NB;
-    }
+    if (last && c.tid < 2 * NB) c.ident = c.tid - NB;  // (rows of A21 leave through the final store pass)
   }
   PSTAMP(0)
 
@@ -286,8 +296,155 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
   panel_step<6, RT>(acc, c);
   panel_step<7, RT>(acc, c);
   PSTAMP(4)
+  if (!last) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int wrow = WROWS * c.wave + 16 * rt + c.g + 4 * q;
+        const int idx = (int)blockIdx.x * PANEL_ROWS + (wrow - NB);
+        if (wrow >= NB && idx < rows_below) {
+          double* dst = A + (int64_t)(NB + idx) * lda + c.r;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) dst[kt * 16] = acc[rt][kt][q];
+        }
+      }
+  }
   if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
   PSTAMP(5)
+}
+
+// ---- split panel (many cells per launch): rows only ---------------------------------------------------
+// potrf_panel_kernel launched with ONE workgroup per cell factors the diagonal block (staged L11, L11^-1 and the
+// 64 reciprocal pivots); this kernel then solves the rows below it, 128 rows per workgroup and no redundant
+// factorisation: L11 comes from the staging area into LDS.  The arithmetic per row -- substitution order, the
+// MFMA updates of the columns right of each 8-column sub-panel and their order -- is that of potrf_panel_kernel
+// with the operands it would have recomputed, so the results are bit-identical; the registers that held the 8 x 8
+// factor are free (3 workgroups per CU instead of 2) and a launch has half as many workgroups.
+constexpr int ROWS_WG = 128;
+constexpr int ROWS_LSTR = NB + 1;  // LDS row stride of the L11 image
+
+template <int P>
+__device__ __forceinline__ void rows_step(d4 (&acc)[2][4], double* __restrict__ sIn, double* __restrict__ sX, const double* __restrict__ sL,
+                                          const double* __restrict__ sRinv, int tid, int wave, int g, int r) {
+  constexpr int C0 = 8 * P;
+  constexpr int KT = C0 / 16;
+  constexpr int HALF = P & 1;
+  if ((r >> 3) == HALF) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sIn[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)] = acc[rt][KT][q];
+  }
+  __syncthreads();
+  if (tid < ROWS_WG) {
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double t = sIn[tid * PSUB + k];
+#pragma unroll
+      for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], sL[(C0 + k) * ROWS_LSTR + C0 + m], t);
+      x[k] = t * sRinv[C0 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sX[tid * PSUB + k] = x[k];
+  }
+  __syncthreads();
+  if ((r >> 3) == HALF) {  // solved values back into the accumulators (see potrf_panel_kernel): one coalesced store pass at the end
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = sX[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)];
+  }
+  if constexpr (C0 + 8 < NB) {
+    constexpr int KT0 = (C0 + 8) / 16;
+    double fa[2][2], fb[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -sX[(32 * wave + 16 * rt + r) * PSUB + 4 * ks + g];
+#pragma unroll
+    for (int kt = KT0; kt < 4; ++kt) {
+      const int kk = kt * 16 + r;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb[kt][ks] = (kk >= C0 + 8) ? sL[kk * ROWS_LSTR + C0 + 4 * ks + g] : 0.0;
+    }
+#pragma unroll
+    for (int kt = KT0; kt < 4; ++kt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
+      }
+  }
+}
+
+// A21: first row below the diagonal block (rows_below rows, lda); stage: this panel's staged L11 (64 x 64) followed by
+// the 64 reciprocal pivots.  grid = (ceil(rows_below / 128), cells).
+__global__ __launch_bounds__(256, 3) void potrf_rows_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
+                                                            const double* __restrict__ stage, int64_t cs) {
+  __shared__ __attribute__((aligned(16))) double sIn[ROWS_WG * PSUB];
+  __shared__ __attribute__((aligned(16))) double sX[ROWS_WG * PSUB];
+  __shared__ __attribute__((aligned(16))) double sL[NB * ROWS_LSTR];
+  __shared__ double sRinv[NB];
+  A21 += (int64_t)blockIdx.y * cs;
+  stage += (int64_t)blockIdx.y * cs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  const int row0 = blockIdx.x * ROWS_WG;
+  // own rows -> accumulator layout, every load unconditional (rows past the end re-read row 0 and are masked)
+  d4 acc[2][4];
+  {
+    const double* rowp[2][4];
+    bool valid[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = row0 + 32 * wave + 16 * rt + g + 4 * q;
+        valid[rt][q] = idx < rows_below;
+        rowp[rt][q] = A21 + (int64_t)(valid[rt][q] ? idx : 0) * lda + r;
+      }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = rowp[rt][q][kt * 16];
+    // L11 image and the reciprocal pivots (staged by the diagonal workgroup of this panel)
+    for (int e = tid; e < NB * NB / 2; e += 256) {
+      const int row = e / (NB / 2), cc = e % (NB / 2);
+      const d2 v = *reinterpret_cast<const d2*>(stage + row * NB + 2 * cc);
+      sL[row * ROWS_LSTR + 2 * cc] = v.x;
+      sL[row * ROWS_LSTR + 2 * cc + 1] = v.y;
+    }
+    if (tid < NB) sRinv[tid] = stage[NB * NB + tid];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = valid[rt][q] ? acc[rt][kt][q] : 0.0;
+  }
+  // (the first barrier inside rows_step<0> also publishes sL / sRinv)
+  rows_step<0>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<1>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<2>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<3>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<4>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<5>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<6>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<7>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = row0 + 32 * wave + 16 * rt + g + 4 * q;
+      if (idx < rows_below) {
+        double* dst = A21 + (int64_t)idx * lda + r;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) dst[kt * 16] = acc[rt][kt][q];
+      }
+    }
 }
 
 // ---- 128-column panel: the same algorithm with a 128 x 128 diagonal block ------------------------
@@ -549,6 +706,7 @@ struct PotrfTuning {
   int panel_rows = 0;    // rows per panel workgroup: 128 (default) or 256
   int panel_occ = 0;     // 3: panel kernel compiled for 3 workgroups per CU (168 registers, small spills) instead of 2
   int inblock = 0;       // 1: right-looking K = 64 strips inside an outer block instead of the recursive halving
+  int split_panel = 0;   // 1: always the split panel (diagonal workgroup + rows kernel), -1: never, 0: from 24 cells per launch on
 };
 inline PotrfTuning& potrf_tuning() {
   static PotrfTuning t = [] {
@@ -559,6 +717,7 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_PANEL_WIDTH")) v.panel_width = atoi(e);
     if (const char* e = getenv("GPRX_PANEL_OCC")) v.panel_occ = atoi(e);
     if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
+    if (const char* e = getenv("GPRX_SPLIT_PANEL")) v.split_panel = atoi(e);
     return v;
   }();
   return t;
@@ -628,6 +787,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   const int bulk_tile = tune.update_tile ? tune.update_tile : (batch > 1 ? 64 : 0);
   bool tail_pending = false;
   hipError_t err = hipSuccess;
+  // split panel (diagonal workgroup, then a rows-only kernel): pays one more dependent launch per panel and wins once
+  // a fused launch would fill the chip with redundant factorisations; bit-identical either way
+  const bool split_panel = tune.split_panel ? tune.split_panel > 0 : batch >= 24;  // measured at N = 4096: -2 % at 16 cells per launch, +5 % at 32
   // one panel: factor the diagonal block at column c and solve every row below it
   auto panel = [&](int c, int pw) {
     const int rows_below = total_rows - c - pw;
@@ -647,6 +809,14 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       const int nchunks = (rows_below + own - 1) / own;
       hipLaunchKernelGGL((potrf_panel_kernel<4, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, c,
                          stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+    } else if (split_panel) {
+      // diagonal block: one workgroup per cell (the `last` role of the panel kernel: L11 staged, L11^-1, pivots) ...
+      hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, c, stage_out, prev_stage,
+                         prev_dst, prev_pw, cs, info_stride);
+      // ... then the rows below it, 128 per workgroup
+      if (rows_below > 0)
+        hipLaunchKernelGGL(potrf_rows_kernel, dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda, lda,
+                           rows_below, (const double*)stage_out, cs);
     } else {
       const int own = PanelGeom<2>::kOwnRows;
       const int nchunks = (rows_below + own - 1) / own;

@@ -184,7 +184,11 @@ int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, doubl
 int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra, double* inv_diag_dev, int* info_host);
 
 /* Process-wide tuning of the Cholesky schedule; value 0 restores the default.  Keys: "panel_width" (64 | 128),
- * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update). */
+ * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update), "no_lookahead"
+ * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
+ * "inblock" (1: right-looking K = 64 strips inside an outer block instead of recursive halving), "split_panel"
+ * (1: always one diagonal workgroup + a rows-only kernel per panel, -1: never; default: from 24 cells per launch on).
+ * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical. */
 int gprx_set_tuning(const char* key, int value);
 
 /* measured back-to-back v_mfma_f64_16x16x4_f64 rate of the whole chip, TFLOP/s */

@@ -140,8 +140,11 @@ def test_potrf_reports_failing_pivot(lib):
         check(rc)
 
 
-@pytest.mark.parametrize("panel,outer,tile", [(64, 256, 0), (128, 128, 128), (64, 512, 64), (128, 256, 64)])
-def test_potrf_large_every_schedule(lib, panel, outer, tile):
+@pytest.mark.parametrize(
+    "panel,outer,tile,split,inblock",
+    [(64, 256, 0, 0, 0), (128, 128, 128, 0, 0), (64, 512, 64, 0, 1), (128, 256, 64, 0, 0), (64, 1024, 0, 1, 0), (64, 512, 64, 1, 1)],
+)
+def test_potrf_large_every_schedule(lib, panel, outer, tile, split, inblock):
     """N = 2048 under several schedules, repeated: catches ordering races that small grids hide (every
     workgroup of a panel launch re-reads the diagonal block, so it must not be overwritten in place
     during that launch; the bulk trailing update runs on a second stream)."""
@@ -153,8 +156,9 @@ def test_potrf_large_every_schedule(lib, panel, outer, tile):
     L_ref = cholesky(spd, lower=True)
     full = np.vstack([spd, rhs])
     try:
-        for key, val in ((b"panel_width", panel), (b"outer_block", outer), (b"update_tile", tile)):
+        for key, val in ((b"panel_width", panel), (b"outer_block", outer), (b"update_tile", tile), (b"split_panel", split), (b"inblock", inblock)):
             check(lib.gprx_set_tuning(key, val))
+        first = None
         for _ in range(3):
             dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
             info = C.c_int(0)
@@ -162,8 +166,35 @@ def test_potrf_large_every_schedule(lib, panel, outer, tile):
             out = dA.to_array((n + extra, n))
             assert rel_err(np.tril(out[:n]), L_ref) < 1e-11
             assert rel_err(out[n:], solve_triangular(L_ref, rhs.T, lower=True).T) < 1e-11
+            if first is None:
+                first = out
+            else:
+                assert np.array_equal(np.tril(out[:n]), np.tril(first[:n]))  # run-to-run reproducible
             dA.free()
             dI.free()
     finally:
-        for key in (b"panel_width", b"outer_block", b"update_tile"):
+        for key in (b"panel_width", b"outer_block", b"update_tile", b"split_panel", b"inblock"):
             lib.gprx_set_tuning(key, 0)
+
+
+def test_split_panel_is_bit_identical_to_the_fused_panel(lib):
+    """The rows-only kernel of the split panel repeats the fused kernel's arithmetic with L11 read from the staging
+    area: the factors must agree bit for bit."""
+    n, extra = 1024, 64
+    rng = np.random.default_rng(2)
+    g = rng.standard_normal((n, 48))
+    full = np.vstack([g @ g.T / 48 + np.eye(n), rng.standard_normal((extra, n))])
+    outs = []
+    try:
+        for split in (-1, 1):
+            check(lib.gprx_set_tuning(b"split_panel", split))
+            dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
+            info = C.c_int(0)
+            check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
+            outs.append((np.tril(dA.to_array((n + extra, n))[:n]), dA.to_array((n + extra, n))[n:], dI.to_array((n // 64, 64, 64))))
+            dA.free()
+            dI.free()
+    finally:
+        lib.gprx_set_tuning(b"split_panel", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
