@@ -40,7 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_TRAIN, DIM, N_TEST = 4096, 8, 100_000
-CELLS_PER_STEP = 32  # cells per batched launch sequence per GPU per step (measured: 1 -> 400, 8 -> 1140, 16 -> 1530, 32 -> 1650 fits/s)
+CELLS_PER_STEP = 64  # cells per batched launch sequence per GPU per step (measured: 1 -> 390, 8 -> 1280, 16 -> 1530, 32 -> 1745, 64 -> 1905 fits/s)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz: half the f32 matrix rate of MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 

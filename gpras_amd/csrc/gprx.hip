@@ -433,12 +433,12 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     for (int k = 0; k < h->d; ++k) row[CELL_PAR_LS + k] = ts[c].ls[k];
     h->slot_ok[c] = 0;
   }
-  // Two groups of cells on two streams (from 32 cells on): the groups run the same launch sequence out of phase, so the
-  // latency-bound panel launches of one overlap the MFMA-bound updates of the other (measured at N = 4096: +2.5 % at 32
-  // cells, +3 % at 64, nothing at 16, -5 % at 8).
-  // Per-cell arithmetic is unchanged.  GPRX_BATCH_GROUPS=1 keeps one group; profiling needs a single stream.
+  // Optional (GPRX_BATCH_GROUPS=2): two groups of cells on two streams run the same launch sequence out of phase, so
+  // the panel launches of one overlap the MFMA-bound updates of the other.  Measured at N = 4096: +2.5 % at 32 cells,
+  // +3 % at 64, nothing at 16, -5 % at 8 -- not worth a default whose per-launch timings depend on what the other
+  // stream happens to run.  Per-cell arithmetic is the same either way.
   static const int env_groups = getenv("GPRX_BATCH_GROUPS") ? atoi(getenv("GPRX_BATCH_GROUPS")) : 0;
-  const int groups = h->profiling ? 1 : (env_groups > 0 ? std::min(env_groups, 2) : (count >= 32 ? 2 : 1));
+  const int groups = (h->profiling || count < 2) ? 1 : (env_groups > 1 ? 2 : 1);
   if (groups > 1 && (rc = ensure_lookahead(h))) return rc;
   HIPCHK(h, hipEventRecord(h->bev[0], st));
   HIPCHK(h, hipMemcpyAsync(h->cellpar.p, par, sizeof(double) * CELL_PAR * count, hipMemcpyHostToDevice, st));
