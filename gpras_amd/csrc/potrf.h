@@ -135,15 +135,6 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[RT][4], PanelCtx& c) {
   if constexpr (P == 1) { PSTAMP(13) }
   __syncthreads();
   if constexpr (P == 1) { PSTAMP(14) }
-  // the solved values return to the accumulators of the lanes that hold these columns: the panel leaves through
-  // one coalesced store pass at the end (16 lanes = one 128-byte line) instead of 16-byte stores scattered over 64
-  // rows per instruction -- 4096 write requests per workgroup that the L2 had to merge
-  if ((c.r >> 3) == HALF) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = c.sX[(WROWS * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)];
-  }
   // C: trailing columns [C0 + 8, 64) of this wave's rows: acc -= X_rows (32 x 8) * X_diag(16 kt .. +15, 8)^T
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
@@ -167,6 +158,16 @@ __device__ __forceinline__ void panel_step(d4 (&acc)[RT][4], PanelCtx& c) {
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
       }
+  }
+  // the solved values return to the accumulators of the lanes that hold these columns: the panel leaves through
+  // one coalesced store pass at the end (16 lanes = one 128-byte line) instead of 16-byte stores scattered over 64
+  // rows per instruction -- 4096 write requests per workgroup that the L2 had to merge.  Issued after the MFMAs so
+  // that the LDS reads run under them (the MFMA on this tile column added exact zeros to the solved columns).
+  if ((c.r >> 3) == HALF) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = c.sX[(WROWS * c.wave + 16 * rt + c.g + 4 * q) * PSUB + (c.r & 7)];
   }
   if constexpr (P == 1) { PSTAMP(15) }
 }
@@ -350,12 +351,6 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[2][4], double* __restrict__ 
     for (int k = 0; k < 8; ++k) sX[tid * PSUB + k] = x[k];
   }
   __syncthreads();
-  if ((r >> 3) == HALF) {  // solved values back into the accumulators (see potrf_panel_kernel): one coalesced store pass at the end
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = sX[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)];
-  }
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
     double fa[2][2], fb[4][2];
@@ -376,6 +371,12 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[2][4], double* __restrict__ 
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
       }
+  }
+  if ((r >> 3) == HALF) {  // solved values back into the accumulators (see potrf_panel_kernel): one coalesced store pass at the end
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = sX[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)];
   }
 }
 
