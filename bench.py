@@ -288,6 +288,54 @@ def main():
         t1 = time.perf_counter()
         gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
         extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
+        # N1: EOF projection either side of the GP path, device-resident: transform (T, cells) -> (T, k)
+        # and reverse (T, k) -> mean + variance fields (T, cells); HBM-bound, rates against the algorithmic bytes
+        from gpras_amd.preprocess import EOFProjector
+        from gpras_amd.synth import make_eof_state
+        from oracle import pca as opca
+
+        t_rows, n_cells, k_modes = 512, 200_000, 10
+        st = make_eof_state(n_cells, k_modes, 64, seed=7)
+        big = np.tile(st["x"], (t_rows // 64, 1))
+        proj = EOFProjector(st["dry"], st["elevations"], st["input_mean"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse", device=device)
+        cp = (n_cells + 15) // 16 * 16
+        padded = np.zeros((t_rows, cp))
+        padded[:, :n_cells] = big
+        dx = DeviceBuffer.from_array(padded, device)
+        dz = DeviceBuffer(8 * t_rows * k_modes, device)
+        dfull, dvfull = DeviceBuffer(8 * t_rows * n_cells, device), DeviceBuffer(8 * t_rows * n_cells, device)
+        times = {"transform": [], "reverse": []}
+        for rep in range(4):
+            t1 = time.perf_counter()
+            check(lib.gprx_pca_transform_dev(proj.handle, dx.ptr, t_rows, dz.ptr))
+            check(lib.gprx_pca_synchronize(proj.handle))
+            times["transform"].append(time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            check(lib.gprx_pca_reverse_dev(proj.handle, dz.ptr, dz.ptr, t_rows, dfull.ptr, dvfull.ptr))
+            check(lib.gprx_pca_synchronize(proj.handle))
+            times["reverse"].append(time.perf_counter() - t1)
+        tt, tr = min(times["transform"][1:]), min(times["reverse"][1:])
+        zs = dz.to_array((t_rows, k_modes))[:64]
+        args = (st["dry"], st["elevations"], st["input_mean"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse")
+        t1 = time.perf_counter()
+        zr = opca.transform(st["x"], *args)
+        tc = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        opca.reverse_transform(zr, np.abs(zr), *args)
+        tcr = time.perf_counter() - t1
+        extra["eof_projection"] = {
+            "shape": {"rows": t_rows, "cells": n_cells, "modes": k_modes},
+            "transform_ms": 1e3 * tt,
+            "transform_GBps_of_input_read_once": 8.0 * t_rows * n_cells / tt / 1e9,
+            "reverse_mean_var_ms": 1e3 * tr,
+            "reverse_GBps_of_output_written_once": 16.0 * t_rows * n_cells / tr / 1e9,
+            "parity_transform_rel_err_vs_oracle": float(np.max(np.abs(zs - zr)) / np.max(np.abs(zr))),
+            "cpu_oracle_rows_per_s": {"transform": 64 / tc, "reverse": 64 / tcr},
+            "gpu_rows_per_s": {"transform": t_rows / tt, "reverse": t_rows / tr},
+        }
+        proj.close()
+        for b in (dx, dz, dfull, dvfull):
+            b.free()
         result["extra"] = extra
 
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----

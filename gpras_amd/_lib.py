@@ -55,6 +55,14 @@ PROTOTYPES = {
     "gprx_dev_free": (C.c_int, [C.c_int, _vp]),
     "gprx_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, _i64]),
     "gprx_memcpy_d2h": (C.c_int, [C.c_int, _vp, _vp, _i64]),
+    "gprx_pca_create": (C.c_int, [C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "gprx_pca_destroy": (C.c_int, [_vp]),
+    "gprx_pca_last_error": (C.c_char_p, [_vp]),
+    "gprx_pca_transform": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gprx_pca_reverse": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "gprx_pca_transform_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gprx_pca_reverse_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "gprx_pca_synchronize": (C.c_int, [_vp]),
     "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),
     "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),
     "gprx_potrf": (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _ip]),

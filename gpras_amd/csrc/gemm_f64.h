@@ -40,6 +40,10 @@ struct GemmArgs {
   int64_t slab;                        // elements per slab
   int inner = 0;                       // > 0: blockIdx.y = cell * inner + entry; cells are cellA / cellB / cellC elements apart
   int64_t cellA = 0, cellB = 0, cellC = 0;
+  // AXF kernels only (TA == 0): A is read as (g(A[m][k]) - a_sub[k]) * a_mul[k], g = max(. - a_elev[k], 0) if a_elev
+  const double* a_sub = nullptr;
+  const double* a_mul = nullptr;
+  const double* a_elev = nullptr;
 };
 
 constexpr int GEMM_BK = 16;
@@ -107,8 +111,10 @@ __device__ __forceinline__ void store_mc(double* s, const d2 (&r)[COLS / 32], in
 // TB == 1: B stored N x K (KC image), op(B) = B^T;  TB == 0: B stored K x N (MC image).
 // PF: fetch C before the main loop (beta != 0, short K: hides the C latency; costs 32 VGPRs on the 64 x 64 tile,
 // i.e. one workgroup of occupancy, so long-K launches use PF = 0)
-template <int TA, int TB, int BM, int BN, int PF = 0>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (PF ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
+// AXF: the A operand is transformed element-wise on its way from memory to LDS (fused centring / weighting of the EOF
+// projection, pca.h): no separate pass over A.
+template <int TA, int TB, int BM, int BN, int PF = 0, int AXF = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : ((PF || AXF) ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
   constexpr int B_ELEMS = TB ? BN * GEMM_LDK : GEMM_BK * McStride<BN>::value;
@@ -221,10 +227,27 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (PF ? 3 : 4)) voi
 
   d2 ra[BM / 32], rb[BN / 32];
   auto gload = [&](int k0) {
-    if constexpr (TA == 0)
+    if constexpr (TA == 0) {
       load_kc<BM>(ra, p.A, p.lda, m0, p.M, k0, tid);
-    else
+      if constexpr (AXF != 0) {
+        // every chunk of this thread has the same two k (q & 7 is the same for q = tid + 256 i)
+        const int kk = k0 + (tid & 7) * 2;
+        const d2 sub = *reinterpret_cast<const d2*>(p.a_sub + kk), mul = *reinterpret_cast<const d2*>(p.a_mul + kk);
+        d2 el = d2{0.0, 0.0};
+        if (p.a_elev) el = *reinterpret_cast<const d2*>(p.a_elev + kk);
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+          d2 v = ra[i];
+          if (p.a_elev) {
+            v.x = fmax(v.x - el.x, 0.0);
+            v.y = fmax(v.y - el.y, 0.0);
+          }
+          ra[i] = d2{(v.x - sub.x) * mul.x, (v.y - sub.y) * mul.y};
+        }
+      }
+    } else {
       load_mc<BM>(ra, p.A, p.lda, m0, p.M, k0, tid);
+    }
     if constexpr (TB == 1)
       load_kc<BN>(rb, p.B, p.ldb, n0, p.N, k0, tid);
     else
@@ -514,6 +537,33 @@ inline hipError_t launch_gemm_splitk(hipStream_t st, int ta, int tb, int M, int 
   if (e != hipSuccess) return e;
   const int64_t total = (int64_t)M * N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)ws, nsplit, M, N, beta, C, ldc);
+  return hipGetLastError();
+}
+
+// split-K NT product with the fused A transform (EOF projection): out = ((g(A) - a_sub) * a_mul) B^T
+inline hipError_t launch_gemm_splitk_axf(hipStream_t st, int M, int N, int K, const double* A, int64_t lda, const double* B, int64_t ldb,
+                                         double* C, int64_t ldc, double* ws, int kchunk, const double* a_sub, const double* a_mul,
+                                         const double* a_elev) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int nsplit = (K + kchunk - 1) / kchunk;
+  GemmArgs p{A, B, ws, lda, ldb, (int64_t)N, M, N, K, 1.0, 0.0, 0, 0, 0, 0, 0, 0, 0, kchunk, (int64_t)M * N};
+  p.a_sub = a_sub;
+  p.a_mul = a_mul;
+  p.a_elev = a_elev;
+  p.tiles_m = (M + 63) / 64;
+  if (N <= 32) {
+    // few output columns (EOF modes): 64 x 32 tiles halve the MFMA work spent on padding columns -- with N = 10 the
+    // 64-wide tile made the projection MFMA-bound instead of HBM-bound
+    p.tiles_n = 1;
+    p.nwg = p.tiles_m;
+    hipLaunchKernelGGL((gemm_f64_kernel<0, 1, 64, 32, 0, 1>), dim3(p.nwg, 1, nsplit), dim3(256), 0, st, p);
+  } else {
+    p.tiles_n = (N + 63) / 64;
+    p.nwg = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL((gemm_f64_kernel<0, 1, 64, 64, 0, 1>), dim3(p.nwg, 1, nsplit), dim3(256), 0, st, p);
+  }
+  const int64_t total = (int64_t)M * N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)ws, nsplit, M, N, 0.0, C, ldc);
   return hipGetLastError();
 }
 

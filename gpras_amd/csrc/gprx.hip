@@ -18,6 +18,7 @@
 #include "gprx_common.h"
 #include "grad.h"
 #include "kmat.h"
+#include "pca.h"
 #include "potrf.h"
 #include "sgpr.h"
 #include "solve.h"
@@ -84,6 +85,16 @@ struct gprx_ctx {
   std::vector<char> slot_ok;
   double batch_ms = 0.0;  // device time of the last batch (events around the whole batch)
   hipEvent_t bev[2] = {nullptr, nullptr};
+};
+
+struct gprx_pca_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t cells = 0, cells_p = 0;  // cells_p: leading dimension of the device copies (multiple of 16, zero padded)
+  int k = 0, depth = 0;
+  Buf mu, wfwd, wrev, elev, E, base, xm, xs;  // per-cell parameters expanded to all cells; E: (k, cells_p)
+  Buf dX, dZ, ws, dMean, dVar, dFull, dVfull;
+  std::string err;
 };
 
 namespace {
@@ -1237,6 +1248,199 @@ int gprx_predict(gprx_handle h, const double* xs, int64_t ns, double* mean, doub
 }
 
 // ---- device memory helpers ---------------------------------------------------------------------
+// ---- EOF projection either side of the GP path ------------------------------
+namespace {
+int pfail(gprx_pca_handle p, int code, const std::string& msg) {
+  if (p) p->err = msg;
+  g_err = msg;
+  return code;
+}
+#define PCACHK(p, expr)                                                                                              \
+  do {                                                                                                               \
+    hipError_t e_ = (expr);                                                                                          \
+    if (e_ != hipSuccess)                                                                                            \
+      return pfail(p, e_ == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+int pensure(gprx_pca_handle p, Buf& b, size_t bytes) {
+  if (b.bytes >= bytes) return GPRX_OK;
+  if (b.p) PCACHK(p, hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  PCACHK(p, hipMalloc((void**)&b.p, bytes));
+  b.bytes = bytes;
+  return GPRX_OK;
+}
+int pupload(gprx_pca_handle p, Buf& b, const std::vector<double>& v) {
+  int rc = pensure(p, b, sizeof(double) * v.size());
+  if (rc) return rc;
+  PCACHK(p, hipMemcpy(b.p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
+  return GPRX_OK;
+}
+// device staging per pass of the host-buffer entry points: 1 GiB of x / output (GPRX_PCA_CHUNK_DOUBLES overrides, for tests)
+int64_t pca_chunk_doubles() {
+  static const int64_t v = getenv("GPRX_PCA_CHUNK_DOUBLES") ? atoll(getenv("GPRX_PCA_CHUNK_DOUBLES")) : ((int64_t)1 << 27);
+  return v;
+}
+}  // namespace
+
+int gprx_pca_create(int device, int64_t n_cells, int k, const unsigned char* dry, const double* elevations, const double* input_mean,
+                    const double* weights, const double* eofs, const double* x_mean, const double* x_std, int depth_mode,
+                    gprx_pca_handle* out) {
+  if (!out) return pfail(nullptr, GPRX_EINVAL, "out is null");
+  *out = nullptr;
+  if (n_cells <= 0 || k <= 0 || k > 64) return pfail(nullptr, GPRX_EINVAL, "n_cells must be positive and 1 <= k <= 64");
+  if (!input_mean || !eofs || !x_mean || !x_std) return pfail(nullptr, GPRX_EINVAL, "input_mean, eofs, x_mean, x_std must be non-null");
+  int64_t n_dry = 0;
+  if (dry)
+    for (int64_t c = 0; c < n_cells; ++c) n_dry += dry[c] != 0;
+  if (depth_mode && !elevations) return pfail(nullptr, GPRX_EINVAL, "depth mode needs the cell elevations");
+  if (!depth_mode && n_dry > 0 && !elevations) return pfail(nullptr, GPRX_EINVAL, "always-dry cells are filled with their elevations: elevations is null");
+  PCACHK(nullptr, hipSetDevice(device));
+  gprx_pca_handle p = new gprx_pca_ctx();
+  p->device = device;
+  p->cells = n_cells;
+  p->cells_p = round_up(n_cells, 16);
+  p->k = k;
+  p->depth = depth_mode ? 1 : 0;
+  const int64_t n_wet = n_cells - n_dry, cp = p->cells_p;
+  // expand the wet-cell parameters to the full cell axis: dry cells get weight 0 (forward) / 1 (reverse), E = 0 and the fill value
+  std::vector<double> mu(cp, 0.0), wf(cp, 0.0), wr(cp, 1.0), el(cp, 0.0), base(cp, 0.0), E((size_t)k * cp, 0.0);
+  int64_t j = 0;
+  for (int64_t c = 0; c < n_cells; ++c) {
+    if (elevations) el[c] = elevations[c];
+    if (dry && dry[c]) {
+      base[c] = depth_mode ? 0.0 : elevations[c];
+      continue;
+    }
+    mu[c] = input_mean[j];
+    wf[c] = weights ? weights[j] : 1.0;
+    wr[c] = wf[c];
+    base[c] = input_mean[j];
+    for (int kk = 0; kk < k; ++kk) E[(size_t)kk * cp + c] = eofs[(size_t)kk * n_wet + j];
+    ++j;
+  }
+  int rc = GPRX_OK;
+  hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete p;
+    return pfail(nullptr, GPRX_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  std::vector<double> xm(x_mean, x_mean + k), xs(x_std, x_std + k);
+  if ((rc = pupload(p, p->mu, mu)) || (rc = pupload(p, p->wfwd, wf)) || (rc = pupload(p, p->wrev, wr)) || (rc = pupload(p, p->elev, el)) ||
+      (rc = pupload(p, p->base, base)) || (rc = pupload(p, p->E, E)) || (rc = pupload(p, p->xm, xm)) || (rc = pupload(p, p->xs, xs))) {
+    gprx_pca_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return GPRX_OK;
+}
+
+int gprx_pca_destroy(gprx_pca_handle p) {
+  if (!p) return GPRX_OK;
+  hipSetDevice(p->device);
+  if (p->stream) hipStreamSynchronize(p->stream);
+  for (Buf* b : {&p->mu, &p->wfwd, &p->wrev, &p->elev, &p->E, &p->base, &p->xm, &p->xs, &p->dX, &p->dZ, &p->ws, &p->dMean, &p->dVar, &p->dFull,
+                 &p->dVfull})
+    if (b->p) hipFree(b->p);
+  if (p->stream) hipStreamDestroy(p->stream);
+  delete p;
+  return GPRX_OK;
+}
+
+// x_dev: (rows, ld) with ld = cells_p (padding columns may hold anything finite: their weight is 0); z_dev: (rows, k)
+int gprx_pca_transform_dev(gprx_pca_handle p, const double* x_dev, int64_t rows, double* z_dev) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (rows < 0 || (rows > 0 && (!x_dev || !z_dev))) return pfail(p, GPRX_EINVAL, "null argument");
+  if (rows == 0) return GPRX_OK;
+  if (rows > (1 << 30)) return pfail(p, GPRX_EINVAL, "too many rows in one call");
+  PCACHK(p, hipSetDevice(p->device));
+  hipStream_t st = p->stream;
+  const int64_t cp = p->cells_p;
+  // Z = ((g(X) - mu) w) E^T in ONE pass over X: the centring / weighting runs inside the GEMM's operand load
+  // (gemm_f64_kernel AXF); M = rows, N = k, K = cells_p cut into slices so that a few thousand workgroups exist
+  const int tiles_m = (int)((rows + 63) / 64);
+  int nsplit = std::max(1, 2048 / tiles_m);
+  int kchunk = (int)round_up((cp + nsplit - 1) / nsplit, 16);
+  if (kchunk < 256) kchunk = 256;
+  nsplit = (int)((cp + kchunk - 1) / kchunk);
+  int rc;
+  if ((rc = pensure(p, p->ws, sizeof(double) * (size_t)nsplit * rows * p->k))) return rc;
+  PCACHK(p, launch_gemm_splitk_axf(st, (int)rows, p->k, (int)cp, x_dev, cp, p->E.p, cp, z_dev, p->k, p->ws.p, kchunk, p->mu.p, p->wfwd.p,
+                                   p->depth ? p->elev.p : nullptr));
+  hipLaunchKernelGGL(pca_standardize_kernel, dim3((unsigned)((rows * p->k + 255) / 256)), dim3(256), 0, st, z_dev, rows, p->k,
+                     (const double*)p->xm.p, (const double*)p->xs.p);
+  PCACHK(p, hipGetLastError());
+  return GPRX_OK;
+}
+
+int gprx_pca_reverse_dev(gprx_pca_handle p, const double* mean_dev, const double* var_dev, int64_t rows, double* full_dev, double* vfull_dev) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (rows < 0 || (rows > 0 && (!mean_dev || !full_dev))) return pfail(p, GPRX_EINVAL, "null argument");
+  if ((var_dev == nullptr) != (vfull_dev == nullptr)) return pfail(p, GPRX_EINVAL, "var and var_full must both be given or both be null");
+  if (rows == 0) return GPRX_OK;
+  PCACHK(p, hipSetDevice(p->device));
+  dim3 grid((unsigned)((p->cells + 255) / 256), (unsigned)std::min<int64_t>((rows + PCA_RB - 1) / PCA_RB, 64));
+  if (p->k <= 16)
+    hipLaunchKernelGGL(pca_reverse_kernel<16>, grid, dim3(256), 0, p->stream, mean_dev, var_dev, rows, p->k, p->cells, (const double*)p->E.p, p->cells_p,
+                       (const double*)p->wrev.p, (const double*)p->base.p, (const double*)p->xm.p, (const double*)p->xs.p, full_dev, vfull_dev);
+  else
+    hipLaunchKernelGGL(pca_reverse_kernel<64>, grid, dim3(256), 0, p->stream, mean_dev, var_dev, rows, p->k, p->cells, (const double*)p->E.p, p->cells_p,
+                       (const double*)p->wrev.p, (const double*)p->base.p, (const double*)p->xm.p, (const double*)p->xs.p, full_dev, vfull_dev);
+  PCACHK(p, hipGetLastError());
+  return GPRX_OK;
+}
+
+int gprx_pca_synchronize(gprx_pca_handle p) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  PCACHK(p, hipStreamSynchronize(p->stream));
+  return GPRX_OK;
+}
+
+int gprx_pca_transform(gprx_pca_handle p, const double* x, int64_t rows, double* z) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (rows < 0 || (rows > 0 && (!x || !z))) return pfail(p, GPRX_EINVAL, "null argument");
+  PCACHK(p, hipSetDevice(p->device));
+  const int64_t cp = p->cells_p, chunk = std::max<int64_t>(64, pca_chunk_doubles() / cp);
+  int rc;
+  for (int64_t t0 = 0; t0 < rows; t0 += chunk) {
+    const int64_t nr = std::min(chunk, rows - t0);
+    if ((rc = pensure(p, p->dX, sizeof(double) * (size_t)nr * cp)) || (rc = pensure(p, p->dZ, sizeof(double) * (size_t)nr * p->k))) return rc;
+    if (cp > p->cells)  // padding columns must be finite (their weight is 0, and 0 * NaN is not)
+      PCACHK(p, hipMemset2DAsync(p->dX.p + p->cells, sizeof(double) * cp, 0, sizeof(double) * (cp - p->cells), nr, p->stream));
+    PCACHK(p, hipMemcpy2DAsync(p->dX.p, sizeof(double) * cp, x + t0 * p->cells, sizeof(double) * p->cells, sizeof(double) * p->cells, nr,
+                               hipMemcpyHostToDevice, p->stream));
+    if ((rc = gprx_pca_transform_dev(p, p->dX.p, nr, p->dZ.p))) return rc;
+    PCACHK(p, hipMemcpyAsync(z + t0 * p->k, p->dZ.p, sizeof(double) * nr * p->k, hipMemcpyDeviceToHost, p->stream));
+    PCACHK(p, hipStreamSynchronize(p->stream));
+  }
+  return GPRX_OK;
+}
+
+int gprx_pca_reverse(gprx_pca_handle p, const double* mean, const double* var, int64_t rows, double* full, double* var_full) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (rows < 0 || (rows > 0 && (!mean || !full))) return pfail(p, GPRX_EINVAL, "null argument");
+  if ((var == nullptr) != (var_full == nullptr)) return pfail(p, GPRX_EINVAL, "var and var_full must both be given or both be null");
+  PCACHK(p, hipSetDevice(p->device));
+  const int64_t chunk = std::max<int64_t>(64, pca_chunk_doubles() / p->cells);
+  int rc;
+  for (int64_t t0 = 0; t0 < rows; t0 += chunk) {
+    const int64_t nr = std::min(chunk, rows - t0);
+    if ((rc = pensure(p, p->dMean, sizeof(double) * (size_t)nr * p->k)) || (rc = pensure(p, p->dFull, sizeof(double) * (size_t)nr * p->cells))) return rc;
+    PCACHK(p, hipMemcpyAsync(p->dMean.p, mean + t0 * p->k, sizeof(double) * nr * p->k, hipMemcpyHostToDevice, p->stream));
+    if (var) {
+      if ((rc = pensure(p, p->dVar, sizeof(double) * (size_t)nr * p->k)) || (rc = pensure(p, p->dVfull, sizeof(double) * (size_t)nr * p->cells))) return rc;
+      PCACHK(p, hipMemcpyAsync(p->dVar.p, var + t0 * p->k, sizeof(double) * nr * p->k, hipMemcpyHostToDevice, p->stream));
+    }
+    if ((rc = gprx_pca_reverse_dev(p, p->dMean.p, var ? p->dVar.p : nullptr, nr, p->dFull.p, var ? p->dVfull.p : nullptr))) return rc;
+    PCACHK(p, hipMemcpyAsync(full + t0 * p->cells, p->dFull.p, sizeof(double) * nr * p->cells, hipMemcpyDeviceToHost, p->stream));
+    if (var) PCACHK(p, hipMemcpyAsync(var_full + t0 * p->cells, p->dVfull.p, sizeof(double) * nr * p->cells, hipMemcpyDeviceToHost, p->stream));
+    PCACHK(p, hipStreamSynchronize(p->stream));
+  }
+  return GPRX_OK;
+}
+
+const char* gprx_pca_last_error(gprx_pca_handle p) { return p ? p->err.c_str() : g_err.c_str(); }
+
 int gprx_dev_malloc(int device, int64_t bytes, void** out) {
   if (!out || bytes < 0) return fail(nullptr, GPRX_EINVAL, "bad argument");
   HIPCHK(nullptr, hipSetDevice(device));

@@ -34,3 +34,26 @@ def make_hydrograph_features(n, d, n_outputs=1, config=0, unit=0):
     y = np.tanh(x @ w) + 0.05 * rng.standard_normal((n, n_outputs))
     y = (y - y.mean(axis=0)) / y.std(axis=0)
     return np.ascontiguousarray(x), np.ascontiguousarray(y)
+
+
+def make_eof_state(n_cells: int, k: int, n_samples: int, seed: int, dry_fraction: float = 0.15, weighted: bool = True):
+    """Synthetic fitted state of an EOF projector and matching fields: orthonormal EOF rows
+    over the wet cells, cell-area-like weights, terrain elevations, water-surface samples of shape (n_samples, n_cells)."""
+    rng = np.random.default_rng(seed)
+    dry = rng.random(n_cells) < dry_fraction
+    n_wet = int(n_cells - dry.sum())
+    elevations = 100.0 + 5.0 * rng.standard_normal(n_cells)
+    q, _ = np.linalg.qr(rng.standard_normal((n_wet, k)))
+    eofs = np.ascontiguousarray(q.T)
+    weights = 0.5 + rng.random(n_wet) if weighted else None
+    modes = rng.standard_normal((n_samples, k)) * np.linspace(3.0, 0.3, k)
+    wse = np.tile(elevations, (n_samples, 1))
+    depth_wet = 1.5 + (modes @ eofs) / (weights if weighted else 1.0) + 0.05 * rng.standard_normal((n_samples, n_wet))
+    wse[:, ~dry] += depth_wet
+    wse[:, dry] -= 0.2  # below the terrain: always dry
+    input_mean = wse[:, ~dry].mean(axis=0)
+    proj = ((wse[:, ~dry] - input_mean) * (weights if weighted else 1.0)) @ eofs.T
+    return {
+        "dry": dry, "elevations": elevations, "input_mean": input_mean, "weights": weights, "eofs": eofs,
+        "x_mean": proj.mean(axis=0), "x_std": proj.std(axis=0), "x": wse,
+    }

@@ -59,6 +59,7 @@ extern "C" {
 #define GPRX_TRAIN_Z 8
 
 typedef struct gprx_ctx* gprx_handle;
+typedef struct gprx_pca_ctx* gprx_pca_handle;
 
 /* ---- library / device -------------------------------------------------------------- */
 int gprx_version(void);
@@ -182,6 +183,28 @@ int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, doubl
  * triangle holds L, the extra rows hold (L^-1 rhs)^T, inv_diag (np/64 blocks of 64x64) holds
  * the inverses of the diagonal blocks.  info_host: 0, or 1-based index of the failing pivot. */
 int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra, double* inv_diag_dev, int* info_host);
+
+/* ---- EOF (PCA) projection either side of the GP path: SURVEY.md section 8(f) row N1 ------------------- */
+/* One projector = the fitted state of a reference PreProcessor (gpras/preprocess.py:868-927): `dry` (n_cells bytes, 1 =
+ * always-dry cell, may be NULL = none), `elevations` (n_cells, needed for depth mode and for filling dry cells in wse mode),
+ * and, over the n_wet = n_cells - sum(dry) wet cells in ascending cell order: `input_mean` (n_wet), `weights` (n_wet or
+ * NULL = unweighted), `eofs` (k, n_wet) row-major; `x_mean`, `x_std` (k).  depth_mode != 0: inputs are water-surface
+ * elevations converted with max(x - elevation, 0) (wse_2_depth, preprocess.py:1040-1044).  1 <= k <= 64. */
+int gprx_pca_create(int device, int64_t n_cells, int k, const unsigned char* dry, const double* elevations, const double* input_mean,
+                    const double* weights, const double* eofs, const double* x_mean, const double* x_std, int depth_mode,
+                    gprx_pca_handle* out);
+int gprx_pca_destroy(gprx_pca_handle p);
+const char* gprx_pca_last_error(gprx_pca_handle p);
+/* PreProcessor.transform (preprocess.py:1009-1038): x (rows, n_cells) -> z (rows, k), host buffers. */
+int gprx_pca_transform(gprx_pca_handle p, const double* x, int64_t rows, double* z);
+/* PreProcessor.reverse_transform (preprocess.py:1052-1085) with _linear_transform_for_var (:1087-1094): mean (rows, k)
+ * [, var (rows, k)] -> full (rows, n_cells) [, var_full (rows, n_cells)]; var and var_full both NULL or both given. */
+int gprx_pca_reverse(gprx_pca_handle p, const double* mean, const double* var, int64_t rows, double* full, double* var_full);
+/* device-resident forms, asynchronous on the projector's stream (gprx_pca_synchronize waits).  x_dev: (rows, ld) with
+ * ld = n_cells rounded up to a multiple of 16 (padding columns: any finite values); outputs as above with ld = k / n_cells. */
+int gprx_pca_transform_dev(gprx_pca_handle p, const double* x_dev, int64_t rows, double* z_dev);
+int gprx_pca_reverse_dev(gprx_pca_handle p, const double* mean_dev, const double* var_dev, int64_t rows, double* full_dev, double* vfull_dev);
+int gprx_pca_synchronize(gprx_pca_handle p);
 
 /* Process-wide tuning of the Cholesky schedule; value 0 restores the default.  Keys: "panel_width" (64 | 128),
  * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update), "no_lookahead"

@@ -1,0 +1,121 @@
+"""EOF projection: CPU pins of the oracle restatement, GPU parity of the HIP path through
+the C ABI.  Tolerances: the projection sums n_wet products per output, so results are compared at 1e-11 relative to the
+largest output (summation order differs between numpy's dot, a hand loop and the split-K MFMA GEMM); the reverse
+transform has k <= 64 terms per output and is held to 1e-13."""
+
+import numpy as np
+import pytest
+
+from gpras_amd.synth import make_eof_state
+from oracle import pca as opca
+
+
+def explicit_transform(st, mode):
+    x = st["x"].astype(float)
+    wet = np.flatnonzero(~st["dry"])
+    out = np.zeros((x.shape[0], st["eofs"].shape[0]))
+    for t in range(x.shape[0]):
+        for k in range(out.shape[1]):
+            s = 0.0
+            for j, c in enumerate(wet):
+                v = x[t, c]
+                if mode == "depth":
+                    v = max(v - st["elevations"][c], 0.0)
+                v = v - st["input_mean_mode"][j]
+                if st["weights"] is not None:
+                    v *= st["weights"][j]
+                s += v * st["eofs"][k, j]
+            out[t, k] = (s - st["x_mean"][k]) / st["x_std"][k]
+    return out
+
+
+def state(n_cells, k, t, seed, mode, weighted=True):
+    st = make_eof_state(n_cells, k, t, seed, weighted=weighted)
+    # the stored mean belongs to the field the projector sees (depths in depth mode)
+    field = opca.wse_2_depth(st["x"].copy(), st["elevations"]) if mode == "depth" else st["x"]
+    st["input_mean_mode"] = field[:, ~st["dry"]].mean(axis=0)
+    return st
+
+
+@pytest.mark.parametrize("mode", ["wse", "depth", "velocity"])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_oracle_against_explicit_loops_and_round_trip(mode, weighted):
+    st = state(37, 4, 5, 11, mode, weighted)
+    args = (st["dry"], st["elevations"], st["input_mean_mode"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], mode)
+    z = opca.transform(st["x"], *args)
+    assert np.allclose(z, explicit_transform(st, mode), rtol=0, atol=1e-12 * np.abs(z).max())
+    full, vfull = opca.reverse_transform(z, np.abs(z) * 0.1, *args)
+    assert full.shape == st["x"].shape and vfull.shape == st["x"].shape
+    assert np.all(vfull[:, st["dry"]] == 0) and np.all(vfull[:, ~st["dry"]] >= 0)
+    if mode == "depth":
+        assert np.all(full[:, st["dry"]] == 0)
+    else:
+        assert np.array_equal(full[:, st["dry"]], np.tile(st["elevations"][st["dry"]], (5, 1)))
+    # projecting the reconstruction again reproduces the mode amplitudes (EOF rows are orthonormal); not in depth mode,
+    # where the clamp at zero is not invertible
+    if mode != "depth":
+        z2 = opca.transform(full, *args)
+        assert np.allclose(z2, z, rtol=0, atol=1e-9 * np.abs(z).max())
+    a2 = opca.linear_transform_for_var(st["weights"], st["eofs"], st["x_std"])
+    assert np.allclose(vfull[:, ~st["dry"]], (np.abs(z) * 0.1) @ a2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,weighted,n_cells,k,t", [("wse", True, 5000, 6, 70), ("depth", True, 3001, 20, 33), ("velocity", False, 777, 3, 150), ("wse", False, 64, 1, 2)])
+def test_gpu_projection_matches_oracle(mode, weighted, n_cells, k, t):
+    from gpras_amd.preprocess import EOFProjector
+
+    st = state(n_cells, k, t, 100 + k, mode, weighted)
+    proj = EOFProjector(st["dry"], st["elevations"], st["input_mean_mode"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], mode)
+    args = (st["dry"], st["elevations"], st["input_mean_mode"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], mode)
+    x_in = st["x"].copy()
+    z = proj.transform(x_in)
+    assert np.array_equal(x_in, st["x"])  # the caller's array is not modified
+    zr = opca.transform(st["x"], *args)
+    assert z.shape == (t, k) and np.max(np.abs(z - zr)) <= 1e-11 * np.max(np.abs(zr))
+    var = 0.05 + 0.01 * np.arange(t * k).reshape(t, k) / (t * k)
+    full, vfull = proj.reverse_transform(zr, var)
+    fr, vr = opca.reverse_transform(zr, var, *args)
+    assert np.max(np.abs(full - fr)) <= 1e-13 * np.max(np.abs(fr))
+    assert np.max(np.abs(vfull - vr)) <= 1e-13 * np.max(np.abs(vr))
+    assert np.array_equal(full[:, st["dry"]], fr[:, st["dry"]]) and np.all(vfull[:, st["dry"]] == 0)
+    only_mean = proj.reverse_transform(zr)
+    assert np.array_equal(only_mean, full)
+    proj.close()
+
+
+@pytest.mark.gpu
+def test_gpu_projection_chunked_rows_and_errors(monkeypatch):
+    """Rows are staged through the device in bounded passes; results do not depend on the pass size."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys; sys.path.insert(0, '.');"
+        "from gpras_amd.preprocess import EOFProjector; from gpras_amd.synth import make_eof_state;"
+        "st = make_eof_state(1000, 5, 300, 3); m = st['x'][:, ~st['dry']].mean(axis=0);"
+        "p = EOFProjector(st['dry'], st['elevations'], m, st['weights'], st['eofs'], st['x_mean'], st['x_std'], 'wse');"
+        "z = p.transform(st['x']); f, v = p.reverse_transform(z, np.abs(z)); np.save(sys.argv[1], np.concatenate([z.ravel(), f.ravel(), v.ravel()]))"
+    )
+    import os
+    import tempfile
+
+    outs = []
+    for chunk in ("65536", "134217728"):  # 64 rows per pass (the minimum) vs one pass
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "o.npy")
+            env = dict(os.environ, GPRX_PCA_CHUNK_DOUBLES=chunk)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1])
+    from gpras_amd.preprocess import EOFProjector
+
+    st = make_eof_state(50, 2, 4, 1)
+    m = st["x"][:, ~st["dry"]].mean(axis=0)
+    with pytest.raises(ValueError):
+        EOFProjector(st["dry"], st["elevations"], m[:-1], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse")
+    with pytest.raises(ValueError):
+        EOFProjector(st["dry"], None, m, st["weights"], st["eofs"], st["x_mean"], st["x_std"], "depth")
+    p = EOFProjector(st["dry"], st["elevations"], m, st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse")
+    with pytest.raises(ValueError):
+        p.transform(st["x"][:, :-1])
