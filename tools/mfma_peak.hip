@@ -26,7 +26,10 @@ int main() {
   struct { int blocks; int threads; double a, b, da; const char* name; } cfg[] = {
       {256, 256, 1.0, 1.0, 1e-9, "1 wave/SIMD, varied operands"}, {1024, 256, 1.0, 1.0, 1e-9, "4 waves/SIMD, varied operands"},
       {1024, 256, 0.0, 0.0, 0.0, "4 waves/SIMD, zero operands"},  {256, 256, 0.0, 0.0, 0.0, "1 wave/SIMD, zero operands"},
-      {128, 256, 1.0, 1.0, 1e-9, "half the CUs, 1 wave/SIMD"}};
+      {128, 256, 1.0, 1.0, 1e-9, "half the CUs, 1 wave/SIMD"},
+      {512, 256, 1.0, 1.0, 1e-9, "2 waves/SIMD, varied operands"},
+      {768, 256, 1.0, 1.0, 1e-9, "3 waves/SIMD, varied operands"},
+      {2048, 256, 1.0, 1.0, 1e-9, "8 waves/SIMD, varied operands"}};
   for (auto& c : cfg) {
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, nullptr);
