@@ -266,50 +266,56 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : ((PF || AXF) ? 3 
       store_mc<BN>(sb, rb, tid);
   };
 
+  // one 16-deep stage: prefetch the next stage's operands into registers, MFMAs on LDS buffer `buf`, publish the
+  // prefetch in the other buffer
+  auto stage = [&](int k0, int buf) {
+    const bool more = (k0 + GEMM_BK) < kend;
+    if (more) gload(k0 + GEMM_BK);
+    const double* sa = smem + buf * (A_ELEMS + B_ELEMS);
+    const double* sb = sa + A_ELEMS;
+    double fa[TM][4], fb[TN][4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int row = wm * (BM / 2) + a * 16 + r;
+      if constexpr (TA == 0) {
+        const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 4 * g);
+        const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 4 * g + 2);
+        fa[a][0] = lo.x; fa[a][1] = lo.y; fa[a][2] = hi.x; fa[a][3] = hi.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[a][j] = sa[(4 * g + j) * McStride<BM>::value + row];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = wn * (BN / 2) + b * 16 + r;
+      if constexpr (TB == 1) {
+        const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 4 * g);
+        const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 4 * g + 2);
+        fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[b][j] = sb[(4 * g + j) * McStride<BN>::value + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+  };
   if (kbeg < kend) {
     gload(kbeg);
     sstore(0);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-      const bool more = (k0 + GEMM_BK) < kend;
-      if (more) gload(k0 + GEMM_BK);
-      const double* sa = smem + buf * (A_ELEMS + B_ELEMS);
-      const double* sb = sa + A_ELEMS;
-      double fa[TM][4], fb[TN][4];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int row = wm * (BM / 2) + a * 16 + r;
-        if constexpr (TA == 0) {
-          const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 4 * g);
-          const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 4 * g + 2);
-          fa[a][0] = lo.x; fa[a][1] = lo.y; fa[a][2] = hi.x; fa[a][3] = hi.y;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) fa[a][j] = sa[(4 * g + j) * McStride<BM>::value + row];
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = wn * (BN / 2) + b * 16 + r;
-        if constexpr (TB == 1) {
-          const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 4 * g);
-          const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 4 * g + 2);
-          fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) fb[b][j] = sb[(4 * g + j) * McStride<BN>::value + col];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
-      if (more) sstore(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
+    // two stages per loop iteration with constant buffer indices: half the taken branches (measured: a taken branch
+    // every 4 MFMAs costs a pure MFMA loop 30 % of its rate, tools/mfma_peak*.hip) and immediate LDS offsets
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * GEMM_BK) {  // (four stages per iteration measured no better)
+      stage(k0, 0);
+      if (k0 + GEMM_BK < kend) stage(k0 + GEMM_BK, 1);
     }
   }
 
