@@ -288,6 +288,44 @@ def main():
         t1 = time.perf_counter()
         gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
         extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
+        # the other sizes of the target: N = 1024 (batched cells) and BASELINE configs[4], N = 16384 d = 12 (one cell alone)
+        sizes = {}
+        x1, y1, _ = make_regression(1024, DIM, n_outputs=cells, n_test=0, config=2, unit=500)
+        h1 = C.c_void_p()
+        check(lib.gprx_create(device, 1024, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h1)))
+        check(lib.gprx_set_data(h1, ptr(x1), ptr(y1), cells), h1)
+        for _ in range(2):
+            check(lib.gprx_factorize_batch(h1, cells, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status)), h1)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            check(lib.gprx_factorize_batch(h1, cells, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status)), h1)
+        sizes["N1024_d8_batched_fits_per_s"] = 10 * cells / (time.perf_counter() - t1)
+        check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
+        sizes["N1024_d8_single_cell_ms"] = 1e2 * (time.perf_counter() - t1)
+        lib.gprx_destroy(h1)
+        n5, d5 = 16384, 12
+        x5, y5, _ = make_regression(n5, d5, n_outputs=1, n_test=0, config=5, unit=0)
+        h5 = C.c_void_p()
+        check(lib.gprx_create(device, n5, d5, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h5)))
+        check(lib.gprx_set_data(h5, ptr(x5), ptr(y5), 1), h5)
+        th5 = np.ascontiguousarray([softplus_inv(1.0), softplus_inv(np.mean(np.abs(x5))), softplus_inv(1.0 - NOISE_LOWER)], dtype=np.float64)
+        check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5)
+        t5 = (time.perf_counter() - t1) / 3
+        ms5 = (C.c_double * 4)()
+        lib.gprx_last_timings(h5, ms5)
+        sizes["N16384_d12_fit_ms"] = 1e3 * t5
+        sizes["N16384_d12_fits_per_s"] = 1.0 / t5
+        sizes["N16384_d12_cholesky_tflops"] = n5**3 / 3 / (ms5[1] * 1e-3) / 1e12
+        sizes["N16384_d12_cholesky_frac_of_fp64_mfma_peak"] = sizes["N16384_d12_cholesky_tflops"] / FP64_MFMA_PEAK_TFLOPS
+        sizes["N16384_d12_kernel_build_GBps"] = (8.0 * n5 * (n5 + 64) / 2 + 8.0 * n5 * d5) / (ms5[0] * 1e-3) / 1e9
+        lib.gprx_destroy(h5)
+        extra["other_sizes"] = sizes
         # N1: EOF projection either side of the GP path, device-resident: transform (T, cells) -> (T, k)
         # and reverse (T, k) -> mean + variance fields (T, cells); HBM-bound, rates against the algorithmic bytes
         from gpras_amd.preprocess import EOFProjector

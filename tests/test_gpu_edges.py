@@ -137,3 +137,73 @@ def test_duplicate_training_points_need_the_noise_term():
         assert np.isfinite(val)
     except np.linalg.LinAlgError:
         pass
+
+
+def test_full_size_4096_batched_cells_against_oracle(lib):
+    """BASELINE configs[1] size: four cells of N = 4096 in one batched launch sequence against the CPU oracle
+    (loss 1e-9; the oracle needs about a second per cell)."""
+    import ctypes as C
+
+    from gpras_amd._lib import check, ptr
+    from oracle import exact as oex
+
+    n, d, cells = 4096, 8, 4
+    x, y, _ = make_regression(n, d, n_outputs=cells, n_test=0, config=2, unit=77)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+    try:
+        rng = np.random.default_rng(4)
+        thetas = np.ascontiguousarray(np.array([0.5413, 0.3, 0.5413]) + rng.uniform(-0.2, 0.2, size=(cells, 3)))
+        units = np.arange(cells, dtype=np.int32)
+        losses = np.zeros(cells)
+        status = np.zeros(cells, dtype=np.int32)
+        check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(losses), ptr(status)), h)
+        for c in range(cells):
+            ref = oex.loss("RBF", x, y[:, c], float(thetas[c, 0]), float(thetas[c, 1]), float(thetas[c, 2]))
+            assert abs(losses[c] - ref) <= 1e-9 * abs(ref)
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_full_size_16384_gradient_matches_central_differences(lib):
+    """BASELINE configs[4] size (N = 16384, d = 12), too large for the oracle: the analytic gradient (L^-1, K^-1, trace
+    pass) must match central differences of the loss (three more factorisations per parameter pair), losses must be
+    reproducible bit for bit, and the predictive variance at training points must lie between the noise and noise + variance."""
+    import ctypes as C
+
+    from gpras_amd._lib import check, ptr
+
+    n, d = 16384, 12
+    x, y, _ = make_regression(n, d, n_outputs=1, n_test=0, config=5, unit=0)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, 2, 0, C.byref(h)))  # Matern-3/2
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    try:
+        theta = np.array([0.4, 0.9, -1.2])
+        loss = C.c_double()
+        grad = np.zeros(3)
+        check(lib.gprx_objective(h, 0, ptr(theta), None, 7, C.byref(loss), ptr(grad)), h)
+        again = C.c_double()
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(again)), h)
+        assert again.value == loss.value
+        eps = 1e-4
+        for k in range(3):
+            lp, lm = C.c_double(), C.c_double()
+            tp, tm = theta.copy(), theta.copy()
+            tp[k] += eps
+            tm[k] -= eps
+            check(lib.gprx_factorize(h, 0, ptr(tp), None, 7, C.byref(lp)), h)
+            check(lib.gprx_factorize(h, 0, ptr(tm), None, 7, C.byref(lm)), h)
+            fd = (lp.value - lm.value) / (2 * eps)
+            assert abs(fd - grad[k]) <= 1e-5 * max(1.0, abs(grad[k])), (k, fd, grad[k])
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(again)), h)
+        xs = np.ascontiguousarray(x[:500])
+        mean, var = np.zeros(500), np.zeros(500)
+        check(lib.gprx_predict(h, ptr(xs), 500, ptr(mean), ptr(var), 1), h)
+        noise = 1e-6 + np.log1p(np.exp(theta[2]))
+        variance = np.log1p(np.exp(theta[0]))
+        assert np.all(var >= noise * (1 - 1e-9)) and np.all(var <= (noise + variance) * (1 + 1e-9))
+        assert np.all(var <= 2.0 * noise + 1e-9)  # at a training point the latent variance is below the noise
+    finally:
+        lib.gprx_destroy(h)
