@@ -290,16 +290,21 @@ def main():
         extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
         # the other sizes of the target: N = 1024 (batched cells) and BASELINE configs[4], N = 16384 d = 12 (one cell alone)
         sizes = {}
-        x1, y1, _ = make_regression(1024, DIM, n_outputs=cells, n_test=0, config=2, unit=500)
+        c1 = 8 * cells  # smaller matrices need more cells per launch to fill the chip
+        x1, y1, _ = make_regression(1024, DIM, n_outputs=c1, n_test=0, config=2, unit=500)
         h1 = C.c_void_p()
         check(lib.gprx_create(device, 1024, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h1)))
-        check(lib.gprx_set_data(h1, ptr(x1), ptr(y1), cells), h1)
+        check(lib.gprx_set_data(h1, ptr(x1), ptr(y1), c1), h1)
+        units1 = np.arange(c1, dtype=np.int32)
+        thetas1 = np.ascontiguousarray(np.tile(thetas, (8, 1)))
+        losses1, status1 = np.zeros(c1), np.zeros(c1, dtype=np.int32)
         for _ in range(2):
-            check(lib.gprx_factorize_batch(h1, cells, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status)), h1)
+            check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
         t1 = time.perf_counter()
         for _ in range(10):
-            check(lib.gprx_factorize_batch(h1, cells, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status)), h1)
-        sizes["N1024_d8_batched_fits_per_s"] = 10 * cells / (time.perf_counter() - t1)
+            check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
+        sizes["N1024_d8_batched_fits_per_s"] = 10 * c1 / (time.perf_counter() - t1)
+        sizes["N1024_d8_cells_per_launch"] = c1
         check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
         t1 = time.perf_counter()
         for _ in range(10):
