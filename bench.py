@@ -288,6 +288,17 @@ def main():
         t1 = time.perf_counter()
         gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
         extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
+        # the sparse path is launch-latency bound (~45 dependent launches per evaluation): independent modes overlap
+        # from several host threads, one engine (handle + stream) each -- GPRAS.fit(workers=8) on 16 modes
+        xs16, ys16, _ = make_regression(n_s, d_s, n_outputs=16, n_test=0, config=6, unit=1)
+        g8 = GPRAS("RBF", device=device)
+        t1 = time.perf_counter()
+        g8.fit(xs16, ys16, m_s, "kmeans", "two-stage", workers=8)
+        t8 = time.perf_counter() - t1
+        extra["sgpr_16_modes_two_stage_fit_seconds_workers8"] = t8
+        extra["sgpr_units_per_s_workers8"] = 16 / t8
+        extra["sgpr_loss_grad_evals_per_s_workers8"] = sum(m.n_evals for m in g8.models) / t8
+        del g8
         # the other sizes of the target: N = 1024 (batched cells) and BASELINE configs[4], N = 16384 d = 12 (one cell alone)
         sizes = {}
         c1 = 8 * cells  # smaller matrices need more cells per launch to fill the chip
