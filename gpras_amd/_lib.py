@@ -45,6 +45,7 @@ PROTOTYPES = {
     "gprx_factorize_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     "gprx_select_slot": (C.c_int, [_vp, C.c_int]),
     "gprx_last_batch_ms": (C.c_int, [_vp, _dp]),
+    "gprx_predict_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_predict": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_predict_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_last_timings": (C.c_int, [_vp, _dp]),

@@ -1248,6 +1248,28 @@ int gprx_predict(gprx_handle h, const double* xs, int64_t ns, double* mean, doub
 }
 
 // ---- device memory helpers ---------------------------------------------------------------------
+int gprx_predict_batch(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
+                       double* means, double* vars, int include_noise) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (count <= 0 || !units || !thetas || ns < 0 || (ns > 0 && (!xs || !means || !vars))) return fail(h, GPRX_EINVAL, "null argument");
+  if (h->m == 0 && h->d <= CELL_PAR - CELL_PAR_LS) {
+    // exact models: all factorisations by one batched launch sequence, then every slot predicts
+    if ((rc = gprx_factorize_batch(h, count, units, thetas, 0, nullptr, nullptr))) return rc;
+    for (int i = 0; i < count; ++i) {
+      if ((rc = select_slot(h, i))) return rc;
+      if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
+    }
+    return GPRX_OK;
+  }
+  for (int i = 0; i < count; ++i) {
+    if ((rc = objective_impl(h, units[i], thetas + (int64_t)i * h->ntheta, z ? z + (int64_t)i * h->m * h->d : nullptr, 0, nullptr, nullptr)))
+      return rc;
+    if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
+  }
+  return GPRX_OK;
+}
+
 // ---- EOF projection either side of the GP path ------------------------------
 namespace {
 int pfail(gprx_pca_handle p, int code, const std::string& msg) {

@@ -184,6 +184,12 @@ int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, doubl
  * the inverses of the diagonal blocks.  info_host: 0, or 1-based index of the failing pivot. */
 int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra, double* inv_diag_dev, int* info_host);
 
+/* The whole predict loop of gpr.py:336-339 in one call: cell i = (units[i], thetas[i], z block i for sparse models) is
+ * factorised (exact models: all cells by one batched launch sequence) and predicts at the shared xs (ns, d);
+ * means / vars: (count, ns) row-major (the transpose of GPRAS.predict's (ns, K)). */
+int gprx_predict_batch(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
+                       double* means, double* vars, int include_noise);
+
 /* ---- EOF (PCA) projection either side of the GP path: SURVEY.md section 8(f) row N1 ------------------- */
 /* One projector = the fitted state of a reference PreProcessor (gpras/preprocess.py:868-927): `dry` (n_cells bytes, 1 =
  * always-dry cell, may be NULL = none), `elevations` (n_cells, needed for depth mode and for filling dry cells in wse mode),

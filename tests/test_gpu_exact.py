@@ -235,3 +235,20 @@ def test_objective_batch_equals_single_calls(lib, kernel, n, d, ard, cells):
             assert single.value == l2[c]
     finally:
         lib.gprx_destroy(h)
+
+
+def test_predict_batch_matches_oracle(lib):
+    """gprx_predict_batch: the per-mode predict loop of gpr.py:336-339 in one call."""
+    n, d, cells, ns = 400, 4, 3, 60
+    x, y, xs = make_regression(n, d, n_outputs=cells, n_test=ns, config=13, unit=2)
+    h = make_handle(lib, n, d, "Matern52", False, x, y)
+    try:
+        thetas = np.ascontiguousarray([pack_theta(1.0 + 0.3 * c, 0.8 + 0.1 * c, 0.05 * (c + 1)) for c in range(cells)])
+        units = np.arange(cells, dtype=np.int32)
+        means, vars_ = np.zeros((cells, ns)), np.zeros((cells, ns))
+        check(lib.gprx_predict_batch(h, cells, ptr(units), ptr(thetas), None, ptr(xs), ns, ptr(means), ptr(vars_), 1), h)
+        for c in range(cells):
+            rm, rv = oex.predict("Matern52", x, y[:, c], 1.0 + 0.3 * c, 0.8 + 0.1 * c, 0.05 * (c + 1), xs)
+            assert np.max(np.abs(means[c] - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(vars_[c] - rv) / rv) <= 1e-8
+    finally:
+        lib.gprx_destroy(h)
