@@ -387,8 +387,22 @@ def main():
             "cpu_oracle_rows_per_s": {"transform": 64 / tc, "reverse": 64 / tcr},
             "gpu_rows_per_s": {"transform": t_rows / tt, "reverse": t_rows / tr},
         }
+        # N3: fused metrics over the reconstructed fields (truth / prediction / confidence: three (T, cells) fields, read once)
+        drow, dcell, darg = DeviceBuffer(8 * t_rows * 4, device), DeviceBuffer(8 * 5 * n_cells, device), DeviceBuffer(4 * 2 * n_cells, device)
+        nmatch = C.c_uint64()
+        tmet = []
+        for rep in range(4):
+            t1 = time.perf_counter()
+            check(lib.gprx_metrics_dev(device, dfull.ptr, dx.ptr, dvfull.ptr, t_rows, n_cells, 2, 0.05, drow.ptr, dcell.ptr, darg.ptr, C.byref(nmatch)))
+            tmet.append(time.perf_counter() - t1)
+        tm = min(tmet[1:])
+        extra["field_metrics"] = {
+            "shape": {"rows": t_rows, "cells": n_cells, "t_tol": 2},
+            "ms": 1e3 * tm,
+            "GBps_of_three_fields_read_once": 24.0 * t_rows * n_cells / tm / 1e9,
+        }
         proj.close()
-        for b in (dx, dz, dfull, dvfull):
+        for b in (dx, dz, dfull, dvfull, drow, dcell, darg):
             b.free()
         result["extra"] = extra
 

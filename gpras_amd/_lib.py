@@ -64,6 +64,8 @@ PROTOTYPES = {
     "gprx_pca_transform_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gprx_pca_reverse_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "gprx_pca_synchronize": (C.c_int, [_vp]),
+    "gprx_metrics": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "gprx_metrics_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),
     "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),
     "gprx_potrf": (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _ip]),

@@ -18,6 +18,7 @@
 #include "gprx_common.h"
 #include "grad.h"
 #include "kmat.h"
+#include "metrics.h"
 #include "pca.h"
 #include "potrf.h"
 #include "sgpr.h"
@@ -1462,6 +1463,66 @@ int gprx_pca_reverse(gprx_pca_handle p, const double* mean, const double* var, i
 }
 
 const char* gprx_pca_last_error(gprx_pca_handle p) { return p ? p->err.c_str() : g_err.c_str(); }
+
+// ---- fused error metrics over reconstructed fields ----------------------------
+int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const double* conf_dev, int64_t rows, int64_t cells, int t_tol,
+                     double v_tol, double* row_sums_dev, double* cell_sums_dev, int* cell_arg_dev, unsigned long long* matches) {
+  if (!x_dev || !y_dev || !row_sums_dev || !cell_sums_dev || !cell_arg_dev || !matches) return fail(nullptr, GPRX_EINVAL, "null argument");
+  if (rows <= 0 || cells <= 0 || rows > (1 << 30)) return fail(nullptr, GPRX_EINVAL, "rows and cells must be positive");
+  if (t_tol < 0 || t_tol > MET_TMAX) return fail(nullptr, GPRX_EINVAL, "t_tol must be between 0 and 8");
+  HIPCHK(nullptr, hipSetDevice(device));
+  const int nwg = (int)((cells + 255) / 256);
+  unsigned long long* match_partial = nullptr;
+  HIPCHK(nullptr, hipMalloc((void**)&match_partial, sizeof(unsigned long long) * nwg));
+  MetricsArgs a{x_dev, y_dev, conf_dev, rows, cells, v_tol, t_tol, cell_sums_dev, cell_sums_dev + cells, cell_sums_dev + 2 * cells,
+                cell_sums_dev + 3 * cells, cell_sums_dev + 4 * cells, cell_arg_dev, cell_arg_dev + cells, match_partial};
+  hipLaunchKernelGGL(metrics_cells_kernel, dim3(nwg), dim3(256), 0, nullptr, a);
+  hipLaunchKernelGGL(metrics_rows_kernel, dim3((unsigned)rows), dim3(256), 0, nullptr, x_dev, y_dev, conf_dev, cells, row_sums_dev);
+  std::vector<unsigned long long> hm(nwg);
+  hipError_t e = hipMemcpy(hm.data(), match_partial, sizeof(unsigned long long) * nwg, hipMemcpyDeviceToHost);  // synchronises
+  hipFree(match_partial);
+  HIPCHK(nullptr, e);
+  unsigned long long total = 0;
+  for (auto v : hm) total += v;
+  *matches = total;
+  return GPRX_OK;
+}
+
+int gprx_metrics(int device, const double* x, const double* y, const double* conf, int64_t rows, int64_t cells, int t_tol, double v_tol,
+                 double* row_sums, double* cell_sums, int* cell_arg, unsigned long long* matches) {
+  if (!x || !y || !row_sums || !cell_sums || !cell_arg || !matches) return fail(nullptr, GPRX_EINVAL, "null argument");
+  if (rows <= 0 || cells <= 0) return fail(nullptr, GPRX_EINVAL, "rows and cells must be positive");
+  HIPCHK(nullptr, hipSetDevice(device));
+  const size_t fb = sizeof(double) * (size_t)rows * cells;
+  double *dx = nullptr, *dy = nullptr, *dc = nullptr, *drow = nullptr, *dcell = nullptr;
+  int* darg = nullptr;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)dx, (void*)dy, (void*)dc, (void*)drow, (void*)dcell, (void*)darg})
+      if (q) hipFree(q);
+  };
+  hipError_t e = hipMalloc((void**)&dx, fb);
+  if (e == hipSuccess) e = hipMalloc((void**)&dy, fb);
+  if (e == hipSuccess && conf) e = hipMalloc((void**)&dc, fb);
+  if (e == hipSuccess) e = hipMalloc((void**)&drow, sizeof(double) * rows * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dcell, sizeof(double) * cells * 5);
+  if (e == hipSuccess) e = hipMalloc((void**)&darg, sizeof(int) * cells * 2);
+  if (e == hipSuccess) e = hipMemcpy(dx, x, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dy, y, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess && conf) e = hipMemcpy(dc, conf, fb, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(nullptr, e == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string("gprx_metrics staging: ") + hipGetErrorString(e));
+  }
+  int rc = gprx_metrics_dev(device, dx, dy, dc, rows, cells, t_tol, v_tol, drow, dcell, darg, matches);
+  if (rc == GPRX_OK) {
+    e = hipMemcpy(row_sums, drow, sizeof(double) * rows * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cell_sums, dcell, sizeof(double) * cells * 5, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cell_arg, darg, sizeof(int) * cells * 2, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(nullptr, GPRX_EHIP, std::string("gprx_metrics copy back: ") + hipGetErrorString(e));
+  }
+  cleanup();
+  return rc;
+}
 
 int gprx_dev_malloc(int device, int64_t bytes, void** out) {
   if (!out || bytes < 0) return fail(nullptr, GPRX_EINVAL, "bad argument");

@@ -212,6 +212,20 @@ int gprx_pca_transform_dev(gprx_pca_handle p, const double* x_dev, int64_t rows,
 int gprx_pca_reverse_dev(gprx_pca_handle p, const double* mean_dev, const double* var_dev, int64_t rows, double* full_dev, double* vfull_dev);
 int gprx_pca_synchronize(gprx_pca_handle p);
 
+/* ---- fused error metrics over two fields: SURVEY.md section 8(f) row N3 (gpras/metrics.py:85-318) ---------- */
+/* Two streaming passes over x (truth), y (prediction) and conf (may be NULL), each (rows, cells) row-major, yield every
+ * reduction the reference's metric functions need:
+ *   row_sums  (rows, 4): per timestep, over cells: sum (x-y), sum (x-y)^2, sum conf, sum |x-y|
+ *   cell_sums (5, cells): per cell, over timesteps: sum (x-y), sum (x-y)^2, sum conf, max_t x, max_t y
+ *   cell_arg  (2, cells): first timestep of the maximum of x and of y (numpy argmax semantics, metrics.py:35-36)
+ *   matches: number of (t, cell) pairs counted by the fidelity index with lag tolerance t_tol (0..8) and value tolerance
+ *            v_tol (metrics.py:187-197). */
+int gprx_metrics(int device, const double* x, const double* y, const double* conf, int64_t rows, int64_t cells, int t_tol, double v_tol,
+                 double* row_sums, double* cell_sums, int* cell_arg, unsigned long long* matches);
+/* same with device-resident fields and outputs (matches is a host pointer; the call synchronises) */
+int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const double* conf_dev, int64_t rows, int64_t cells, int t_tol,
+                     double v_tol, double* row_sums_dev, double* cell_sums_dev, int* cell_arg_dev, unsigned long long* matches);
+
 /* Process-wide tuning of the Cholesky schedule; value 0 restores the default.  Keys: "panel_width" (64 | 128),
  * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update), "no_lookahead"
  * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
