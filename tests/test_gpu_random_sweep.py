@@ -1,0 +1,101 @@
+"""Seeded random sweep over (kernel, N, d, ARD, units, M, hyperparameters): single calls, batched calls and the sparse
+model against the CPU oracle -- loss 1e-9, gradient 1e-7, predictions 1e-8 (the tolerance BASELINE.json's north_star
+states), batched results bit-identical to single calls."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpras_amd import _lib
+from gpras_amd._lib import check, ptr
+from gpras_amd.synth import make_regression
+from oracle import exact as oex
+from oracle import kernels as okn
+from oracle import sgpr as osg
+from oracle import transforms as otr
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    kernel = okn.KERNEL_NAMES[rng.integers(len(okn.KERNEL_NAMES))]
+    n = int(rng.choice([rng.integers(2, 64), rng.integers(64, 200), rng.integers(200, 900)]))
+    d = int(rng.integers(1, 13))
+    ard = bool(rng.integers(2))
+    units = int(rng.integers(1, 4))
+    return rng, kernel, n, d, ard, units
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_exact_single_and_batched(lib, seed):
+    rng, kernel, n, d, ard, units = draw(1000 + seed)
+    x, y, xs = make_regression(n, d, n_outputs=units, n_test=9, config=20, unit=seed)
+    nl = d if ard else 1
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS[kernel], int(ard), C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), units), h)
+    try:
+        cells = int(rng.integers(2, 6))
+        cunits = np.ascontiguousarray(rng.integers(0, units, size=cells), dtype=np.int32)
+        variance = rng.uniform(0.3, 3.0, cells)
+        ls = rng.uniform(0.4, 2.5, (cells, nl))
+        noise = 10.0 ** rng.uniform(-2.5, 0.0, cells)
+        thetas = np.ascontiguousarray(
+            [np.concatenate([[otr.unconstrain(variance[c], ls[c], noise[c])[0]], np.atleast_1d(otr.unconstrain(variance[c], ls[c], noise[c])[1]),
+                             [otr.unconstrain(variance[c], ls[c], noise[c])[2]]]) for c in range(cells)]
+        )
+        losses, grads = np.zeros(cells), np.zeros((cells, 2 + nl))
+        check(lib.gprx_objective_batch(h, cells, ptr(cunits), ptr(thetas), None, 7, ptr(losses), ptr(grads)), h)
+        for c in range(cells):
+            th = np.ascontiguousarray(thetas[c])
+            wl = th[1:-1] if ard else float(th[1])
+            ref_loss, g = oex.loss_and_grad(kernel, x, y[:, cunits[c]], float(th[0]), wl, float(th[-1]))
+            ref = np.concatenate([[g["variance"]], np.atleast_1d(g["lengthscales"]), [g["noise"]]])
+            assert abs(losses[c] - ref_loss) <= 1e-9 * max(abs(ref_loss), 1.0), (kernel, n, d, ard)
+            assert np.max(np.abs(grads[c] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref))), (kernel, n, d, ard)
+            single, g1 = C.c_double(), np.zeros(2 + nl)
+            check(lib.gprx_objective(h, int(cunits[c]), ptr(th), None, 7, C.byref(single), ptr(g1)), h)
+            assert single.value == losses[c] and np.array_equal(g1, grads[c])
+            mean, var = np.zeros(9), np.zeros(9)
+            check(lib.gprx_predict(h, ptr(xs), 9, ptr(mean), ptr(var), 1), h)
+            lsc = ls[c] if ard else float(ls[c, 0])
+            rm, rv = oex.predict(kernel, x, y[:, cunits[c]], float(variance[c]), lsc, float(noise[c]), xs)
+            assert np.max(np.abs(mean - rm)) <= 1e-8 * max(np.max(np.abs(rm)), 1e-3)
+            assert np.max(np.abs(var - rv) / rv) <= 1e-8
+    finally:
+        lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sparse(lib, seed):
+    rng, kernel, n, d, ard, units = draw(2000 + seed)
+    n = max(n, 8)
+    m = int(rng.integers(1, min(n, 130) + 1))
+    x, y, xs = make_regression(n, d, n_outputs=units, n_test=9, config=21, unit=seed)
+    nl = d if ard else 1
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, m, okn.KERNEL_IDS[kernel], int(ard), C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), units), h)
+    try:
+        unit = int(rng.integers(units))
+        variance, ls, noise = float(rng.uniform(0.3, 3.0)), rng.uniform(0.5, 2.0, nl), float(10.0 ** rng.uniform(-2.0, 0.0))
+        wv, wl, wn = otr.unconstrain(variance, ls, noise)
+        theta = np.ascontiguousarray(np.concatenate([[wv], np.atleast_1d(wl), [wn]]))
+        z = np.ascontiguousarray(x[rng.choice(n, size=m, replace=False)] + 1e-3 * rng.standard_normal((m, d)))
+        loss, grad = C.c_double(), np.zeros(2 + nl + m * d)
+        check(lib.gprx_objective(h, unit, ptr(theta), ptr(z), 15, C.byref(loss), ptr(grad)), h)
+        wl_arg = theta[1:-1] if ard else float(theta[1])
+        ref_loss, g = osg.loss_and_grad(kernel, x, y[:, unit], z, float(theta[0]), wl_arg, float(theta[-1]))
+        ref = np.concatenate([[g["variance"]], np.atleast_1d(g["lengthscales"]), [g["noise"]], np.asarray(g["Z"]).ravel()])
+        assert abs(loss.value - ref_loss) <= 1e-9 * max(abs(ref_loss), 1.0), (kernel, n, d, m, ard)
+        assert np.max(np.abs(grad - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref))), (kernel, n, d, m, ard)
+        mean, var = np.zeros(9), np.zeros(9)
+        check(lib.gprx_predict(h, ptr(xs), 9, ptr(mean), ptr(var), 1), h)
+        lsc = ls if ard else float(ls[0])
+        rm, rv = osg.predict(kernel, x, y[:, unit], z, variance, lsc, noise, xs)
+        assert np.max(np.abs(mean - rm)) <= 1e-8 * max(np.max(np.abs(rm)), 1e-3)
+        assert np.max(np.abs(var - rv) / rv) <= 1e-8
+    finally:
+        lib.gprx_destroy(h)
