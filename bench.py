@@ -288,9 +288,26 @@ def main():
         t1 = time.perf_counter()
         gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
         extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
-        # the sparse path is launch-latency bound (~45 dependent launches per evaluation): independent modes overlap
-        # from several host threads, one engine (handle + stream) each -- GPRAS.fit(workers=8) on 16 modes
+        # the sparse path is launch-latency bound (~45 dependent launches per evaluation): all modes go through the SAME
+        # launches (gprx_objective_batch, cell index in every grid) -- 16 cells per call, then the default two-stage fit
+        # of 16 modes in lock step; for comparison the older scheme, one engine + host thread per mode (workers=8)
         xs16, ys16, _ = make_regression(n_s, d_s, n_outputs=16, n_test=0, config=6, unit=1)
+        g16s = GPRAS("RBF", device=device)
+        g16s._init_models(xs16.astype(np.float64), ys16.astype(np.float64), m_s, "kmeans")
+        u16 = np.arange(16, dtype=np.int32)
+        th16 = np.stack([mm.theta() for mm in g16s.models])
+        z16 = np.stack([mm.Z for mm in g16s.models])
+        g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
+        extra["sgpr_batched16_loss_grad_evals_per_s"] = 20 * 16 / (time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        g16s.fit(xs16, ys16, m_s, "kmeans", "two-stage")
+        tl = time.perf_counter() - t1
+        extra["sgpr_16_modes_two_stage_fit_seconds_lockstep"] = tl
+        extra["sgpr_units_per_s_lockstep"] = 16 / tl
+        del g16s
         g8 = GPRAS("RBF", device=device)
         t1 = time.perf_counter()
         g8.fit(xs16, ys16, m_s, "kmeans", "two-stage", workers=8)

@@ -44,6 +44,9 @@ struct GemmArgs {
   const double* a_sub = nullptr;
   const double* a_mul = nullptr;
   const double* a_elev = nullptr;
+  // per-cell alpha (two-level batches): alpha = alpha_tab[cell * alpha_stride] when alpha_tab is set
+  const double* alpha_tab = nullptr;
+  int alpha_stride = 0;
 };
 
 constexpr int GEMM_BK = 16;
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : ((PF || AXF) ? 3 
       p.A += (int64_t)cell * p.cellA;
       p.B += (int64_t)cell * p.cellB;
       p.C += (int64_t)cell * p.cellC;
+      if (p.alpha_tab) p.alpha = p.alpha_tab[(int64_t)cell * p.alpha_stride];
     }
     p.A += (int64_t)entry * p.strideA;
     p.B += (int64_t)entry * p.strideB;
@@ -486,14 +490,16 @@ inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A,
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0, int batch = 1,
                               int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0, int cells = 1, int64_t cellA = 0,
-                              int64_t cellB = 0, int64_t cellC = 0) {
+                              int64_t cellB = 0, int64_t cellC = 0, const double* alpha_tab = nullptr, int alpha_stride = 0) {
   GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC, 0, 0};
   if (M <= 0 || N <= 0 || batch <= 0 || cells <= 0) return hipSuccess;
-  if (cells > 1) {  // two-level batch: `batch` entries per cell
+  if (cells > 1 || alpha_tab) {  // two-level batch: `batch` entries per cell
     p.inner = batch;
     p.cellA = cellA;
     p.cellB = cellB;
     p.cellC = cellC;
+    p.alpha_tab = alpha_tab;
+    p.alpha_stride = alpha_stride;
     batch *= cells;
   }
   static const int force_tile = getenv("GPRX_FORCE_TILE") ? atoi(getenv("GPRX_FORCE_TILE")) : 0;  // experiments
@@ -519,7 +525,9 @@ inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int 
 // ---- split-K for skinny products (few output tiles, long K) -------------------------------------------
 // out[i][j] = beta * out[i][j] + sum_z slab_z[i][j]   (fixed summation order: deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __restrict__ ws, int nsplit, int M, int N, double beta,
-                                                            double* __restrict__ C, int64_t ldc) {
+                                                            double* __restrict__ C, int64_t ldc, int64_t ws_cell = 0, int64_t c_cell = 0) {
+  ws += (int64_t)blockIdx.y * ws_cell;  // blockIdx.y = cell
+  C += (int64_t)blockIdx.y * c_cell;
   const int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x;
   if (e >= (int64_t)M * N) return;
   const int i = (int)(e / N), j = (int)(e % N);
@@ -531,18 +539,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double* __rest
 
 // C = alpha op(A) op(B) + beta C with K cut into slices of `kchunk` (multiple of 16) over blockIdx.z; ws must hold
 // ceil(K / kchunk) * M * N doubles.  No triangular flags.
+// cells > 1: the same product for `cells` operand sets cellA / cellB / cellC doubles apart, workspaces ws_cell apart
+// (each >= ceil(K / kchunk) * M * N), per-cell alpha from alpha_tab[cell * alpha_stride] if given.
 inline hipError_t launch_gemm_splitk(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
-                                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws, int kchunk) {
-  if (M <= 0 || N <= 0) return hipSuccess;
+                                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ws, int kchunk, int cells = 1,
+                                     int64_t cellA = 0, int64_t cellB = 0, int64_t cellC = 0, int64_t ws_cell = 0,
+                                     const double* alpha_tab = nullptr, int alpha_stride = 0) {
+  if (M <= 0 || N <= 0 || cells <= 0) return hipSuccess;
   const int nsplit = (K + kchunk - 1) / kchunk;
   GemmArgs p{A, B, ws, lda, ldb, (int64_t)N, M, N, K, alpha, 0.0, 0, 0, 0, 0, 0, 0, 0, kchunk, (int64_t)M * N};
+  if (cells > 1 || alpha_tab) {
+    p.inner = 1;
+    p.cellA = cellA;
+    p.cellB = cellB;
+    p.cellC = ws_cell;
+    p.alpha_tab = alpha_tab;
+    p.alpha_stride = alpha_stride;
+  }
   hipError_t e = hipErrorInvalidValue;
-  if (ta == 0 && tb == 1) e = launch_gemm_t<0, 1, 64, 64>(st, p, 1, nsplit);
-  if (ta == 0 && tb == 0) e = launch_gemm_t<0, 0, 64, 64>(st, p, 1, nsplit);
-  if (ta == 1 && tb == 0) e = launch_gemm_t<1, 0, 64, 64>(st, p, 1, nsplit);
+  if (ta == 0 && tb == 1) e = launch_gemm_t<0, 1, 64, 64>(st, p, cells, nsplit);
+  if (ta == 0 && tb == 0) e = launch_gemm_t<0, 0, 64, 64>(st, p, cells, nsplit);
+  if (ta == 1 && tb == 0) e = launch_gemm_t<1, 0, 64, 64>(st, p, cells, nsplit);
   if (e != hipSuccess) return e;
   const int64_t total = (int64_t)M * N;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)ws, nsplit, M, N, beta, C, ldc);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256), cells), dim3(256), 0, st, (const double*)ws, nsplit, M, N, beta, C,
+                     ldc, ws_cell, cellC);
   return hipGetLastError();
 }
 

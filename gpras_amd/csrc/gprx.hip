@@ -78,6 +78,10 @@ struct gprx_ctx {
   // batched exact factorisations (gprx_factorize_batch): `arena_slots` cell blocks, `cell_stride` doubles apart, each
   // [K (np + 64) x np | invD np x 64 | staged diagonal blocks np x 128 | alpha np]; parameter / result tables, one row per cell
   Buf arena, cellpar, cellres, garena, gpartial;  // garena: per cell [L^-1 | K^-1] for batched gradients
+  Buf sarena;                                   // batched sparse models: one cell block per slot (sgpr_batch_layout)
+  int sarena_slots = 0;
+  double* spin = nullptr;  // pinned staging of the sparse batch: parameters up, reductions / gradients down
+  size_t spin_doubles = 0;
   double* bpin = nullptr;  // pinned: [slots][CELL_PAR] parameters up, then [slots][CELL_RES] results down
   int arena_slots = 0;
   int64_t cell_stride = 0, off_invd = 0, off_stage = 0, off_alpha = 0;
@@ -697,8 +701,8 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   } else {
     HIPCHK(h, launch_gemm(st, 0, 1, mp, mp, np, 1.0 / s, h->Am.p, np, h->Am.p, np, 0.0, h->Bm.p, mp, 0));
   }
-  hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0);
-  hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0, h->red.p + 2);
+  hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256), dim3(256), 0, st, h->Bm.p, (int64_t)mp, mp, 1.0, (int64_t)0);
+  hipLaunchKernelGGL(diag_sum_kernel, dim3(1), dim3(256), 0, st, (const double*)h->Bm.p, (int64_t)mp, mp, 1.0, h->red.p + 2, (int64_t)0);
   if ((rc = ensure(h, h->SM, sizeof(double) * (size_t)SM_COUNT * mp * mp))) return rc;
   HIPCHK(h, hipMemcpyAsync(sm(h, SM_BFULL), h->Bm.p, sizeof(double) * (size_t)mp * mp, hipMemcpyDeviceToDevice, st));
   // appended row: A' y / s  -> comes out of the Cholesky as c
@@ -773,7 +777,7 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   HIPCHK(h, trsv_lower(st, h->Bm.p, mp, h->invDB.p, mvec, mp, true));
   HIPCHK(h, trsv_lower(st, h->Qm.p, mp, h->invDL.p, mvec, mp, true));
   hipLaunchKernelGGL(sgpr_combine_kernel, dim3((mp * mp + 255) / 256), dim3(256), 0, st, (const double*)Qinv, (const double*)Sinv,
-                     (const double*)T1, (const double*)mvec, mp, W, GQ);
+                     (const double*)T1, (const double*)mvec, mp, W, GQ, (int64_t)0);
   HIPCHK(h, launch_gemm(st, 0, 0, mp, np, mp, 1.0, W, mp, h->P.p, np, 0.0, h->WP.p, np, 0));
   // contractions with the kernel derivatives
   double* partP = h->partial.p;
@@ -789,12 +793,12 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
                      (int64_t)np, (const double*)h->WHQ.p, (int64_t)mp, (const double*)h->invls.p, m, n, d, h->dZ.p);
   // noise terms: |y - P^T m|^2 and tr(B^-1) = |LB^-1|_F^2
   HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, h->P.p, np, mvec, 1, 0.0, qvec, 1, 0, 64));
-  hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1), dim3(256), 0, st, yu, (const double*)qvec, n, h->red.p + 4);
+  hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1), dim3(256), 0, st, yu, (const double*)qvec, n, h->red.p + 4, (int64_t)0, (int64_t)0);
   {
     const int nb = mp < 64 ? mp : 64;
     double* part = h->vecs.p + 2 * mp;  // scratch inside the vector block
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, part);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, (const double*)part, nb, h->red.p + 3);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, part, (int64_t)0);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, st, (const double*)part, nb, h->red.p + 3, (int64_t)0);
   }
   std::vector<double> hs(2 * width), hz((size_t)m * d);
   double red[5];
@@ -816,6 +820,256 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   g[1 + h->nlen] = (tr_sinv_pp - tr_qinv_pp + red[4] + nn * t.variance) / (2.0 * s * s) - nn / (2.0 * s);
   if (gz) std::memcpy(gz, hz.data(), sizeof(double) * m * d);
   return GPRX_OK;
+}
+
+// ---- batched sparse models ------------------------------------------------------------------------------------
+// The reference fits its per-mode SGPR models one after the other (gpr.py:272-274); every evaluation is ~45 tiny
+// dependent launches (M = 50 inducing points: every M x M matrix is one 64 x 64 tile), i.e. pure launch latency.
+// Here `count` cells (unit, theta, Z) on the handle's x go through the SAME launch sequence, the cell index in a grid
+// dimension of every kernel: each cell owns one block of `ss` doubles holding all its matrices at fixed offsets, so
+// a kernel adds blockIdx * ss to its per-cell pointers; hyperparameters (and 1 / s for the GEMM scalings) come from the
+// cell-parameter table.  Same kernels, same per-element operation order as sgpr_factorize / sgpr_gradient:
+// bit-identical values.
+struct SgprLayout {
+  int64_t oZ, oY, oP, oAm, oQm, oBm, oInvDL, oInvDB, oSM, oWP, oWHP, oWHQ, oVecs, odZ, oStage, oPart, oWs, oRed, ss;
+  int64_t part_p, part_q;
+  int width, nsplit;
+};
+
+SgprLayout sgpr_batch_layout(gprx_handle h) {
+  const int64_t mp = h->mp, np = h->np, m = h->m, d = h->d;
+  SgprLayout L{};
+  L.width = 2 + (int)d;
+  L.nsplit = (int)((np + SPLITK_CHUNK - 1) / SPLITK_CHUNK);
+  L.part_p = (mp / KM_T) * (np / KM_T) * L.width;
+  L.part_q = (mp / KM_T) * (mp / KM_T) * L.width;
+  int64_t o = 0;
+  auto take = [&](int64_t doubles) {
+    const int64_t at = o;
+    o += round_up(doubles, 64);
+    return at;
+  };
+  L.oZ = take(m * d);
+  L.oY = take(np);
+  L.oP = take(mp * np);
+  L.oAm = take(mp * np);
+  L.oQm = take(mp * mp);
+  L.oBm = take((mp + NB) * mp);
+  L.oInvDL = take(mp * NB);
+  L.oInvDB = take(mp * NB);
+  L.oSM = take((int64_t)SM_COUNT * mp * mp);
+  L.oWP = take(mp * np);
+  L.oWHP = take(mp * np);
+  L.oWHQ = take(mp * mp);
+  L.oVecs = take(4 * mp + np);
+  L.odZ = take(m * d);
+  L.oStage = take(mp * PW);
+  L.oPart = take(L.part_p + L.part_q + 2 * L.width);
+  L.oWs = take((int64_t)L.nsplit * mp * mp);
+  L.oRed = take(8);
+  L.ss = o;
+  return L;
+}
+
+int ensure_sarena(gprx_handle h, int slots, const SgprLayout& L) {
+  if (h->sarena_slots >= slots) return GPRX_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->sarena.p) HIPCHK(h, hipFree(h->sarena.p));
+  h->sarena.p = nullptr;
+  h->sarena.bytes = 0;
+  h->sarena_slots = 0;
+  int rc;
+  if ((rc = ensure(h, h->sarena, sizeof(double) * (size_t)L.ss * slots))) return rc;
+  HIPCHK(h, hipMemset(h->sarena.p, 0, sizeof(double) * (size_t)L.ss * slots));  // padding of every matrix stays zero
+  if ((rc = ensure(h, h->cellpar, sizeof(double) * CELL_PAR * slots))) return rc;
+  if ((rc = ensure(h, h->cellres, sizeof(double) * CELL_RES * slots))) return rc;
+  const size_t need = (size_t)slots * (CELL_PAR + CELL_RES + 8 + 2 * L.width + h->m * h->d);
+  if (h->spin_doubles < need) {
+    if (h->spin) HIPCHK(h, hipHostFree(h->spin));
+    h->spin = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&h->spin, sizeof(double) * need, hipHostMallocDefault));
+    h->spin_doubles = need;
+  }
+  h->sarena_slots = slots;
+  return GPRX_OK;
+}
+
+// elbo_out[c] (NaN if a Cholesky failed), g: count x ntheta constrained-parameter derivatives, gz: count x m x d (host);
+// g / gz may be null (loss only).  status[c]: GPRX_OK / GPRX_ENOTPD.
+int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta* ts, const double* zs, double* elbo_out, double* g, double* gz,
+                         int* status) {
+  const SgprLayout L = sgpr_batch_layout(h);
+  int rc;
+  if ((rc = ensure_sarena(h, count, L))) return rc;
+  const int mp = (int)h->mp, np = (int)h->np, m = (int)h->m, n = (int)h->n, d = h->d;
+  const int64_t ss = L.ss, mm = (int64_t)mp * mp;
+  const size_t pitch = sizeof(double) * (size_t)ss;
+  hipStream_t st = h->stream;
+  double* A0 = h->sarena.p;
+  double* par = h->spin;
+  for (int c = 0; c < count; ++c) {
+    double* row = par + (size_t)c * CELL_PAR;
+    std::memset(row, 0, sizeof(double) * CELL_PAR);
+    row[0] = ts[c].variance;
+    row[1] = ts[c].noise;
+    row[2] = (double)units[c];
+    row[3] = 1.0 / ts[c].noise;
+    for (int k = 0; k < d; ++k) row[CELL_PAR_LS + k] = ts[c].ls[k];
+  }
+  HIPCHK(h, hipMemcpyAsync(h->cellpar.p, par, sizeof(double) * CELL_PAR * count, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(h->cellres.p, 0, sizeof(double) * CELL_RES * count, st));
+  HIPCHK(h, hipMemcpy2DAsync(A0 + L.oZ, pitch, zs, sizeof(double) * m * d, sizeof(double) * m * d, count, hipMemcpyHostToDevice, st));
+  const double* cpar = h->cellpar.p;
+  const double* inv_s = cpar + 3;  // alpha table: 1 / s, CELL_PAR apart
+  hipLaunchKernelGGL(gather_y_kernel, dim3((np + 255) / 256, count), dim3(256), 0, st, (const double*)h->Y.p, np, cpar, CELL_PAR, A0 + L.oY, ss);
+  // ---- factorisation (sgpr_factorize) ----
+  KmatArgs kp{A0 + L.oZ, h->X.p, nullptr, A0 + L.oP, np, m, n, d, mp, np, 0.0, 0.0, 0, 0.0, nullptr, 0};
+  kp.cell_par = cpar;
+  kp.out_stride = ss;
+  kp.a_stride = ss;
+  kp.diag_const = 1;
+  HIPCHK(h, launch_kmat(st, h->kid, kp, count));
+  KmatArgs kq{A0 + L.oZ, A0 + L.oZ, nullptr, A0 + L.oQm, mp, m, m, d, mp, mp, 0.0, JITTER, 2, 1.0, nullptr, 0};
+  kq.cell_par = cpar;
+  kq.out_stride = ss;
+  kq.a_stride = ss;
+  kq.b_stride = ss;
+  kq.diag_const = 1;
+  HIPCHK(h, launch_kmat(st, h->kid, kq, count));
+  int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
+  HIPCHK(h, potrf_lower(st, A0 + L.oQm, mp, mp, 0, A0 + L.oInvDL, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES));
+  HIPCHK(h, hipMemcpy2DAsync(A0 + L.oAm, pitch, A0 + L.oP, pitch, sizeof(double) * (size_t)mp * np, count, hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, trsm_lower_left(st, A0 + L.oQm, mp, A0 + L.oInvDL, A0 + L.oAm, np, mp, np, count, ss));
+  if (mp <= 512 && np >= 4 * SPLITK_CHUNK) {
+    HIPCHK(h, launch_gemm_splitk(st, 0, 1, mp, mp, np, 0.0, A0 + L.oAm, np, A0 + L.oAm, np, 0.0, A0 + L.oBm, mp, A0 + L.oWs, SPLITK_CHUNK, count, ss, ss,
+                                 ss, ss, inv_s, CELL_PAR));
+  } else {
+    HIPCHK(h, launch_gemm(st, 0, 1, mp, mp, np, 0.0, A0 + L.oAm, np, A0 + L.oAm, np, 0.0, A0 + L.oBm, mp, 0, 0, 1, 0, 0, 0, count, ss, ss, ss, inv_s,
+                          CELL_PAR));
+  }
+  hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256, count), dim3(256), 0, st, A0 + L.oBm, (int64_t)mp, mp, 1.0, ss);
+  hipLaunchKernelGGL(diag_sum_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, mp, 1.0, A0 + L.oRed + 2, ss);
+  double* SM0 = A0 + L.oSM;
+  auto smb = [&](int slot) { return SM0 + (size_t)slot * mm; };
+  HIPCHK(h, hipMemcpy2DAsync(smb(SM_BFULL), pitch, A0 + L.oBm, pitch, sizeof(double) * (size_t)mm, count, hipMemcpyDeviceToDevice, st));
+  double* crow = A0 + L.oBm + mm;
+  HIPCHK(h, hipMemset2DAsync(crow, pitch, 0, sizeof(double) * (size_t)NB * mp, count, st));
+  if (np >= 4 * SPLITK_CHUNK) {
+    HIPCHK(h, launch_gemm_splitk(st, 0, 0, mp, 1, np, 0.0, A0 + L.oAm, np, A0 + L.oY, 1, 0.0, crow, 1, A0 + L.oWs, SPLITK_CHUNK, count, ss, ss, ss, ss,
+                                 inv_s, CELL_PAR));
+  } else {
+    HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 0.0, A0 + L.oAm, np, A0 + L.oY, 1, 0.0, crow, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss, inv_s, CELL_PAR));
+  }
+  HIPCHK(h, potrf_lower(st, A0 + L.oBm, mp, mp, NB, A0 + L.oInvDB, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES));
+  hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, (const double*)crow, mp,
+                     A0 + L.oRed, ss, (int)ss);
+  // ---- gradient (sgpr_gradient) ----
+  double *Linv = smb(SM_LINV), *LBinv = smb(SM_LBINV), *Qinv = smb(SM_QINV), *Sinv = smb(SM_SINV), *R = smb(SM_R), *T1 = smb(SM_T1),
+         *T2 = smb(SM_T2), *W = smb(SM_W), *GQ = smb(SM_GQ), *Bfull = smb(SM_BFULL);
+  double* mvec = A0 + L.oVecs;
+  double* qvec = A0 + L.oVecs + 4 * mp;
+  double* partP = A0 + L.oPart;
+  double* partQ = partP + L.part_p;
+  double* sums = partQ + L.part_q;
+  const int tiles_m = mp / KM_T, tiles_n = np / KM_T, width = L.width;
+  if (g) {
+    auto gemm_mm = [&](int ta, int tb, const double* A, const double* B, double* C, int flags) {
+      return launch_gemm(st, ta, tb, mp, mp, mp, 1.0, A, mp, B, mp, 0.0, C, mp, flags, 0, 1, 0, 0, 0, count, ss, ss, ss);
+    };
+    HIPCHK(h, hipMemset2DAsync(Linv, pitch, 0, sizeof(double) * (size_t)mm, count, st));
+    HIPCHK(h, trtri_lower(st, A0 + L.oQm, mp, A0 + L.oInvDL, Linv, mp, T1, mp, mp, count, ss, ss));
+    HIPCHK(h, hipMemset2DAsync(LBinv, pitch, 0, sizeof(double) * (size_t)mm, count, st));
+    HIPCHK(h, trtri_lower(st, A0 + L.oBm, mp, A0 + L.oInvDB, LBinv, mp, T1, mp, mp, count, ss, ss));
+    HIPCHK(h, gemm_mm(1, 0, Linv, Linv, Qinv, GEMM_A_UPPER | GEMM_B_LOWER));
+    HIPCHK(h, gemm_mm(0, 0, LBinv, Linv, R, GEMM_A_LOWER | GEMM_B_LOWER));
+    HIPCHK(h, gemm_mm(1, 0, R, R, Sinv, GEMM_A_UPPER | GEMM_B_LOWER));
+    HIPCHK(h, gemm_mm(0, 0, Bfull, Linv, T2, GEMM_B_LOWER));
+    HIPCHK(h, gemm_mm(1, 0, Linv, T2, T1, GEMM_A_UPPER));
+    hipLaunchKernelGGL(copy_row_batch_kernel, dim3((mp + 255) / 256, count), dim3(256), 0, st, (const double*)crow, mvec, mp, ss);
+    HIPCHK(h, trsv_lower(st, A0 + L.oBm, mp, A0 + L.oInvDB, mvec, mp, true, count, ss));
+    HIPCHK(h, trsv_lower(st, A0 + L.oQm, mp, A0 + L.oInvDL, mvec, mp, true, count, ss));
+    hipLaunchKernelGGL(sgpr_combine_kernel, dim3((mp * mp + 255) / 256, count), dim3(256), 0, st, (const double*)Qinv, (const double*)Sinv,
+                       (const double*)T1, (const double*)mvec, mp, W, GQ, ss);
+    HIPCHK(h, launch_gemm(st, 0, 0, mp, np, mp, 1.0, W, mp, A0 + L.oP, np, 0.0, A0 + L.oWP, np, 0, 0, 1, 0, 0, 0, count, ss, ss, ss));
+    TraceArgs tp{A0 + L.oZ, h->X.p, nullptr, A0 + L.oWP, np, mvec, A0 + L.oY, 0.0, 0.0, m, n, d, 0.0, 0, partP, A0 + L.oWHP, np, tiles_n};
+    tp.cell_par = cpar;
+    tp.w_stride = ss;
+    tp.uv_stride = ss;
+    tp.partial_stride = ss;
+    tp.a_stride = ss;
+    tp.wh_stride = ss;
+    tp.scale_inv_noise = 1;
+    HIPCHK(h, launch_trace(st, h->kid, tp, tiles_m * tiles_n, count));
+    TraceArgs tq{A0 + L.oZ, A0 + L.oZ, nullptr, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, 0.0, 0, partQ, A0 + L.oWHQ, mp, tiles_m};
+    tq.cell_par = cpar;
+    tq.w_stride = ss;
+    tq.partial_stride = ss;
+    tq.a_stride = ss;
+    tq.b_stride = ss;
+    tq.wh_stride = ss;
+    HIPCHK(h, launch_trace(st, h->kid, tq, tiles_m * tiles_m, count));
+    hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums, ss, ss);
+    hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width, ss, ss);
+    hipLaunchKernelGGL(dz_kernel, dim3(m * d, count), dim3(256), 0, st, (const double*)(A0 + L.oZ), (const double*)h->X.p,
+                       (const double*)(A0 + L.oWHP), (int64_t)np, (const double*)(A0 + L.oWHQ), (int64_t)mp, (const double*)nullptr, m, n, d,
+                       A0 + L.odZ, ss, cpar);
+    HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, A0 + L.oP, np, mvec, 1, 0.0, qvec, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss));
+    hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oY), (const double*)qvec, n, A0 + L.oRed + 4, ss,
+                       ss);
+    const int nb = mp < 64 ? mp : 64;
+    double* part = A0 + L.oVecs + 2 * mp;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb, count), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, part, ss);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1, count), dim3(64), 0, st, (const double*)part, nb, A0 + L.oRed + 3, ss);
+  }
+  // ---- results: reductions, pivot status, trace sums, dZ ----
+  double* hres = h->spin + (size_t)count * CELL_PAR;                // CELL_RES per cell
+  double* hred = hres + (size_t)count * CELL_RES;                   // 8 per cell
+  double* hsum = hred + (size_t)count * 8;                          // 2 * width per cell
+  double* hdz = hsum + (size_t)count * 2 * width;                   // m * d per cell
+  HIPCHK(h, hipMemcpyAsync(hres, h->cellres.p, sizeof(double) * CELL_RES * count, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpy2DAsync(hred, sizeof(double) * 8, A0 + L.oRed, pitch, sizeof(double) * 8, count, hipMemcpyDeviceToHost, st));
+  if (g) {
+    HIPCHK(h, hipMemcpy2DAsync(hsum, sizeof(double) * 2 * width, sums, pitch, sizeof(double) * 2 * width, count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpy2DAsync(hdz, sizeof(double) * m * d, A0 + L.odZ, pitch, sizeof(double) * m * d, count, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->factorized = false;  // the single-model state of the handle is untouched but no longer "the last evaluation"
+  int first_error = GPRX_OK;
+  const double nn = (double)h->n;
+  for (int c = 0; c < count; ++c) {
+    int info = 0;
+    std::memcpy(&info, hres + (size_t)c * CELL_RES + 2, sizeof(int));
+    if (status) status[c] = info == 0 ? GPRX_OK : GPRX_ENOTPD;
+    if (info != 0) {
+      if (!first_error) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "cell %d: Kuu or B not positive definite: pivot %d", c, info);
+        first_error = fail(h, GPRX_ENOTPD, msg);
+      }
+      elbo_out[c] = std::numeric_limits<double>::quiet_NaN();
+      continue;
+    }
+    const double* red = hred + (size_t)c * 8;
+    const double s = ts[c].noise, v = ts[c].variance;
+    elbo_out[c] = -0.5 * nn * std::log(2.0 * M_PI) - red[0] - 0.5 * nn * std::log(s) - 0.5 * (nn * v / s - red[2]) -
+                  0.5 * (h->yy[units[c]] / s - red[1]);
+    if (!g) continue;
+    const double* hs = hsum + (size_t)c * 2 * width;
+    double* gc = g + (size_t)c * h->ntheta;
+    const double tr_sinv_pp = s * ((double)mp - red[3]);
+    const double tr_qinv_pp = s * red[2];
+    gc[0] = -nn / (2.0 * s) + hs[0] + hs[width];
+    if (h->ard) {
+      for (int k = 0; k < d; ++k) gc[1 + k] = hs[2 + k] + hs[width + 2 + k];
+    } else {
+      double acc = 0.0;
+      for (int k = 0; k < d; ++k) acc += hs[2 + k] + hs[width + 2 + k];
+      gc[1] = acc;
+    }
+    gc[1 + h->nlen] = (tr_sinv_pp - tr_qinv_pp + red[4] + nn * v) / (2.0 * s * s) - nn / (2.0 * s);
+    if (gz) std::memcpy(gz + (size_t)c * m * d, hdz + (size_t)c * m * d, sizeof(double) * m * d);
+  }
+  return first_error;
 }
 
 int check_handle(gprx_handle h) {
@@ -892,9 +1146,10 @@ int gprx_destroy(gprx_handle h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
                  &h->pred, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs, &h->dZ,
-                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial})
+                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial, &h->sarena})
     if (b->p && !b->borrowed) hipFree(b->p);
   if (h->bpin) hipHostFree(h->bpin);
+  if (h->spin) hipHostFree(h->spin);
   for (auto& ev : h->bev)
     if (ev) hipEventDestroy(ev);
   if (h->info) hipFree(h->info);
@@ -1126,6 +1381,37 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
           for (int k = 0; k < h->ntheta; ++k) gi[k] = std::numeric_limits<double>::quiet_NaN();
         }
       }
+    }
+    return frc;
+  }
+  static const bool no_sparse_batch = getenv("GPRX_NO_SPARSE_BATCH") != nullptr;  // escape hatch: one model after the other
+  if (h->m != 0 && count > 1 && h->d <= CELL_PAR - CELL_PAR_LS && !no_sparse_batch) {
+    if (!z) return fail(h, GPRX_EINVAL, "z (inducing inputs) is null for a sparse model");
+    const int64_t nz = h->m * h->d;
+    for (int64_t e = 0; e < (int64_t)count * nz; ++e)
+      if (!std::isfinite(z[e])) return fail(h, GPRX_EINVAL, "z is not finite");
+    std::vector<Theta> ts(count);
+    for (int i = 0; i < count; ++i) {
+      if (units[i] < 0 || units[i] >= h->n_units) return fail(h, GPRX_EINVAL, "unit out of range (call gprx_set_data first)");
+      for (int k = 0; k < h->ntheta; ++k)
+        if (!std::isfinite(theta[(int64_t)i * h->ntheta + k])) return fail(h, GPRX_EINVAL, "theta is not finite");
+      ts[i] = decode_theta(h, theta + (int64_t)i * h->ntheta);
+    }
+    std::vector<double> elbo(count), g(grads ? (size_t)count * h->ntheta : 0), gzv(grads ? (size_t)count * nz : 0);
+    std::vector<int> st(count);
+    const int frc = sgpr_objective_batch(h, count, units, ts.data(), z, elbo.data(), grads ? g.data() : nullptr, grads ? gzv.data() : nullptr, st.data());
+    if (frc != GPRX_OK && frc != GPRX_ENOTPD) return frc;
+    for (int i = 0; i < count; ++i) {
+      losses[i] = -(elbo[i] + log_prior(h, ts[i], mask));  // NaN for a failed cell
+      if (!grads) continue;
+      double* gi = grads + (int64_t)i * gw;
+      if (st[i] != GPRX_OK) {
+        for (int64_t k = 0; k < gw; ++k) gi[k] = std::numeric_limits<double>::quiet_NaN();
+        continue;
+      }
+      chain_rule(h, ts[i], mask, g.data() + (size_t)i * h->ntheta, gi);
+      double* gzi = gi + h->ntheta;
+      for (int64_t e = 0; e < nz; ++e) gzi[e] = (mask & GPRX_TRAIN_Z) ? -gzv[(size_t)i * nz + e] : 0.0;
     }
     return frc;
   }

@@ -34,6 +34,8 @@ struct TraceArgs {
   // partial advanced by their per-cell strides
   const double* cell_par = nullptr;
   int64_t w_stride = 0, uv_stride = 0, partial_stride = 0;
+  int64_t a_stride = 0, b_stride = 0, v_stride = -1, wh_stride = 0;  // v_stride < 0: v advances like u
+  int scale_inv_noise = 0;  // 1: w_scale = uv_scale = 1 / table[1] (the sparse model's 1 / s)
 };
 
 // One workgroup per 64 x 64 tile.  Thread mapping as kmat_kernel: 8 rows x 2 columns per thread.
@@ -51,9 +53,13 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
     p.W += (int64_t)blockIdx.y * p.w_stride;
     if (p.u) {
       p.u += (int64_t)blockIdx.y * p.uv_stride;
-      p.v += (int64_t)blockIdx.y * p.uv_stride;
+      p.v += (int64_t)blockIdx.y * (p.v_stride < 0 ? p.uv_stride : p.v_stride);
     }
     p.partial += (int64_t)blockIdx.y * p.partial_stride;
+    p.a += (int64_t)blockIdx.y * p.a_stride;
+    p.b += (int64_t)blockIdx.y * p.b_stride;
+    if (p.wh_out) p.wh_out += (int64_t)blockIdx.y * p.wh_stride;
+    if (p.scale_inv_noise) p.w_scale = p.uv_scale = par[3];
   }
   const int ti = blockIdx.x / p.tiles_n, tj = blockIdx.x % p.tiles_n;
   double* out = p.partial + (int64_t)blockIdx.x * (2 + p.d);
@@ -181,8 +187,17 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
 // algebraically equal  z rowsum(WH) - WH X  cancels catastrophically on near-coincident points.
 __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, const double* __restrict__ X, const double* __restrict__ WHP,
                                                  int64_t ldp, const double* __restrict__ WHQ, int64_t ldq, const double* __restrict__ ls,
-                                                 int m, int n, int d, double* __restrict__ dZ) {
+                                                 int m, int n, int d, double* __restrict__ dZ, int64_t cs = 0,
+                                                 const double* __restrict__ cell_par = nullptr) {
   __shared__ double sred[4];
+  if (cell_par) {  // batched: blockIdx.y = cell; Z, WHP, WHQ, dZ live in the cell block, lengthscales in the table
+    const int64_t off = (int64_t)blockIdx.y * cs;
+    Z += off;
+    WHP += off;
+    WHQ += off;
+    dZ += off;
+    ls = cell_par + (int64_t)blockIdx.y * CELL_PAR + CELL_PAR_LS;
+  }
   const int i = blockIdx.x / d, k = blockIdx.x % d;
   const double z = Z[(int64_t)i * d + k];
   double acc = 0.0;
@@ -197,10 +212,10 @@ __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, c
 
 // out[e] = sum over workgroups of partial[wg][e]
 __global__ __launch_bounds__(64) void trace_final(const double* __restrict__ partial, int nwg, int width, double* __restrict__ out,
-                                                  int64_t partial_stride = 0) {
+                                                  int64_t partial_stride = 0, int64_t out_stride = -1) {
   const int e = blockIdx.x;
-  partial += (int64_t)blockIdx.y * partial_stride;  // batched: blockIdx.y = cell, results width apart
-  out += (int64_t)blockIdx.y * width;
+  partial += (int64_t)blockIdx.y * partial_stride;  // batched: blockIdx.y = cell, results width (or out_stride) apart
+  out += (int64_t)blockIdx.y * (out_stride < 0 ? width : out_stride);
   double s = 0.0;
   for (int w = threadIdx.x; w < nwg; w += 64) s += partial[(int64_t)w * width + e];
   s = wave_sum(s);

@@ -82,6 +82,8 @@ struct KmatArgs {
   // cell-parameter table, CELL_PAR doubles per row: [0] variance, [1] diag_add, [2] unit, [8 .. 8 + d) lengthscales
   const double* cell_par = nullptr;
   int64_t out_stride = 0;
+  int64_t a_stride = 0, b_stride = 0;  // per-cell point sets (inducing inputs); 0: shared
+  int diag_const = 0;                  // 1: keep diag_add as given (jitter) instead of the table's [1]
 };
 constexpr int CELL_PAR = 72;
 constexpr int CELL_PAR_LS = 8;
@@ -97,11 +99,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   const int i0 = ti * KM_T, j0 = tj * KM_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cp = lane & 31, rsub = lane >> 5;
+  double diag_keep = p.diag_add;
   if (p.cell_par) {
     const double* par = p.cell_par + (int64_t)blockIdx.y * CELL_PAR;
     p.ls = par + CELL_PAR_LS;
     p.dparams = par;
     p.out += (int64_t)blockIdx.y * p.out_stride;
+    p.a += (int64_t)blockIdx.y * p.a_stride;
+    p.b += (int64_t)blockIdx.y * p.b_stride;
   }
 
   double acc[8][2];
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
 
   if (p.dparams) {
     p.variance = p.dparams[0];
-    p.diag_add = p.dparams[1];
+    p.diag_add = p.diag_const ? diag_keep : p.dparams[1];
   }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {

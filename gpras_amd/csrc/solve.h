@@ -121,16 +121,18 @@ inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const
 }
 
 // ---- matrix right-hand side: L X = B (in place), recursive halving onto MFMA GEMMs -------------
+// cells > 1: the same solve for `cells` systems whose L, inv_diag and B are all cs doubles apart
 inline hipError_t trsm_lower_left(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* B, int64_t ldb,
-                                  int n, int ncols) {
-  if (n == NB) return launch_gemm(st, 0, 0, NB, ncols, NB, 1.0, inv_diag, NB, B, ldb, 0.0, B, ldb, GEMM_A_LOWER, 64);
+                                  int n, int ncols, int cells = 1, int64_t cs = 0) {
+  if (n == NB) return launch_gemm(st, 0, 0, NB, ncols, NB, 1.0, inv_diag, NB, B, ldb, 0.0, B, ldb, GEMM_A_LOWER, 64, 1, 0, 0, 0, cells, cs, cs, cs);
   const int n1 = (n / NB / 2) * NB, n2 = n - n1;
-  hipError_t e = trsm_lower_left(st, L, lda, inv_diag, B, ldb, n1, ncols);
+  hipError_t e = trsm_lower_left(st, L, lda, inv_diag, B, ldb, n1, ncols, cells, cs);
   if (e != hipSuccess) return e;
-  e = launch_gemm(st, 0, 0, n2, ncols, n1, -1.0, L + (int64_t)n1 * lda, lda, B, ldb, 1.0, B + (int64_t)n1 * ldb, ldb, 0);
+  e = launch_gemm(st, 0, 0, n2, ncols, n1, -1.0, L + (int64_t)n1 * lda, lda, B, ldb, 1.0, B + (int64_t)n1 * ldb, ldb, 0, 0, 1, 0, 0, 0, cells, cs,
+                  cs, cs);
   if (e != hipSuccess) return e;
   return trsm_lower_left(st, L + (int64_t)n1 * lda + n1, lda, inv_diag + (int64_t)(n1 / NB) * NB * NB, B + (int64_t)n1 * ldb, ldb, n2,
-                         ncols);
+                         ncols, cells, cs);
 }
 
 // L^T X = B (in place)

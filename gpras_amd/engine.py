@@ -92,18 +92,23 @@ class Engine:
             check(rc, self._h)
         return losses, status == 0
 
-    def objective_batch(self, units, thetas, mask: int, want_grad: bool = True):
-        """Exact models: ``training_loss`` (and gradient w.r.t. theta) of ``len(units)`` cells by batched launches
-        (``gprx_objective_batch``).  Returns ``(losses, grads or None, ok)``; failed cells hold NaN."""
-        if self.m != 0:
-            raise ValueError("objective_batch is for exact models")
+    def objective_batch(self, units, thetas, mask: int, want_grad: bool = True, zs=None):
+        """``training_loss`` (and gradient ``[d theta | d Z]``) of ``len(units)`` cells by batched launches
+        (``gprx_objective_batch``): exact models, or sparse models with one ``Z`` per cell in ``zs (cells, M, d)``.
+        Returns ``(losses, grads or None, ok)``; failed cells hold NaN."""
         units = np.ascontiguousarray(units, dtype=np.int32)
         thetas = as_f64(thetas)
         if thetas.shape != (units.size, self.n_theta):
             raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
+        zp = None
+        if self.m != 0:
+            zs = as_f64(zs)
+            if zs.shape != (units.size, self.m, self.d):
+                raise ValueError(f"zs must be ({units.size}, {self.m}, {self.d})")
+            zp = ptr(zs)
         losses = np.empty(units.size)
-        grads = np.zeros((units.size, self.n_theta)) if want_grad else None
-        rc = self._lib.gprx_objective_batch(self._h, units.size, ptr(units), ptr(thetas), None, mask, ptr(losses), ptr(grads) if want_grad else None)
+        grads = np.zeros((units.size, self.n_theta + self.m * self.d)) if want_grad else None
+        rc = self._lib.gprx_objective_batch(self._h, units.size, ptr(units), ptr(thetas), zp, mask, ptr(losses), ptr(grads) if want_grad else None)
         if rc not in (_lib.GPRX_OK, _lib.GPRX_ENOTPD):
             check(rc, self._h)
         return losses, grads, np.isfinite(losses)

@@ -70,9 +70,9 @@ class GPRAS:
     ) -> None:
         """Fit one GP per column of ``y`` (gpr.py:237-275).
 
-        ``lockstep`` (extension, exact models): the per-mode optimisers run in lock step, every round of
-        evaluations as one batched launch sequence on the GPU (``gpras_amd.lockstep``); the fitted parameters equal
-        the serial loop's bit for bit.  Default: on for exact models with more than one mode and ``workers == 1``.
+        ``lockstep`` (extension): the per-mode optimisers run in lock step, every round of evaluations as one
+        batched launch sequence on the GPU (``gpras_amd.lockstep``); the fitted parameters equal the serial loop's
+        bit for bit.  Default: on whenever there is more than one mode and ``workers == 1``.
 
         ``workers > 1`` (extension): the per-mode loop, serial in the reference (gpr.py:272-274), runs from
         that many host threads, each with its own engine (handle + HIP stream) on the same GPU, so the many
@@ -82,9 +82,9 @@ class GPRAS:
         self.y = y.astype(np.float64)
         opt = OPTIMIZERS[optimization_method]  # KeyError before any device work, as the reference (gpr.py:272)
         self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard, workers=workers)
-        can_lockstep = n_inducing is None and len(self.models) > 1 and len(self.engines) == 1 and hasattr(self.engine, "objective_batch")
+        can_lockstep = len(self.models) > 1 and len(self.engines) == 1 and hasattr(self.engine, "objective_batch")
         if lockstep and not can_lockstep:
-            raise ValueError("lockstep fitting needs an exact model (n_inducing=None) with several modes on one engine")
+            raise ValueError("lockstep fitting needs several modes on one engine (workers=1)")
         if can_lockstep and (lockstep is None or lockstep):
             from .lockstep import fit_lockstep
 

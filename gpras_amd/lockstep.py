@@ -1,4 +1,4 @@
-"""Lock-step fitting of the independent per-mode models of one ``GPRAS`` (exact models).
+"""Lock-step fitting of the independent per-mode models of one ``GPRAS`` (exact and sparse models).
 
 The reference fits its modes one after the other (``/root/reference/gpras/gpr.py:272-274``); every optimiser
 step of a mode is one ``training_loss`` (+ gradient) evaluation, and the modes share nothing but ``x``.  Here
@@ -24,15 +24,16 @@ class LockstepEvaluator:
         self.engine = engine
         self.cv = threading.Condition()
         self.active = n_workers
-        self.pending: dict[int, tuple[int, np.ndarray, int, bool]] = {}
+        self.pending: dict[int, tuple[int, np.ndarray, int, bool, Any]] = {}
         self.results: dict[int, Any] = {}
         self.batches = 0  # launch sequences issued (for tests / reporting)
         self.cells = 0    # evaluations served
 
     # -- worker side ---------------------------------------------------------------------------------
-    def evaluate(self, wid: int, unit: int, theta, mask: int, want_grad: bool):
+    def evaluate(self, wid: int, unit: int, theta, z, mask: int, want_grad: bool):
         with self.cv:
-            self.pending[wid] = (int(unit), np.array(theta, dtype=np.float64), int(mask), bool(want_grad))
+            zc = None if z is None else np.array(z, dtype=np.float64)
+            self.pending[wid] = (int(unit), np.array(theta, dtype=np.float64), int(mask), bool(want_grad), zc)
             if len(self.pending) >= self.active:
                 self._flush()
             else:
@@ -53,17 +54,21 @@ class LockstepEvaluator:
     # -- batch (called with the lock held; the waiting workers hold nothing) -----------------------------
     def _flush(self) -> None:
         groups: dict[tuple[int, bool], list[int]] = {}
-        for wid, (_, _, mask, want_grad) in self.pending.items():
+        for wid, (_, _, mask, want_grad, _) in self.pending.items():
             groups.setdefault((mask, want_grad), []).append(wid)
         for (mask, want_grad), wids in groups.items():
             try:
                 if len(wids) == 1:
-                    unit, theta, _, _ = self.pending[wids[0]]
-                    self.results[wids[0]] = self.engine.objective(unit, theta, None, mask, want_grad=want_grad)
+                    unit, theta, _, _, zc = self.pending[wids[0]]
+                    self.results[wids[0]] = self.engine.objective(unit, theta, zc, mask, want_grad=want_grad)
                 else:
                     units = [self.pending[w][0] for w in wids]
                     thetas = np.stack([self.pending[w][1] for w in wids])
-                    losses, grads, ok = self.engine.objective_batch(units, thetas, mask, want_grad=want_grad)
+                    zs = None if self.pending[wids[0]][4] is None else np.stack([self.pending[w][4] for w in wids])
+                    if zs is None:
+                        losses, grads, ok = self.engine.objective_batch(units, thetas, mask, want_grad=want_grad)
+                    else:
+                        losses, grads, ok = self.engine.objective_batch(units, thetas, mask, want_grad=want_grad, zs=zs)
                     for k, w in enumerate(wids):
                         if ok[k]:
                             self.results[w] = (float(losses[k]), grads[k].copy() if want_grad else None)
@@ -90,7 +95,7 @@ class LockstepBackend:
         return getattr(self._engine, name)
 
     def objective(self, unit, theta, z, mask, want_grad=True):
-        return self._evaluator.evaluate(self._wid, unit, theta, mask, want_grad)
+        return self._evaluator.evaluate(self._wid, unit, theta, z, mask, want_grad)
 
 
 def fit_lockstep(models, optimizer: Callable[..., Any], opt_kwargs: dict[str, Any], max_batch: int = 32) -> dict[str, int]:

@@ -141,11 +141,12 @@ int gprx_last_profile(gprx_handle h, double* out8);
 /* Evaluate loss (+ gradient) for `count` units in one call: units[i] with theta row i
  * (count, n_theta) and z block i (count, m, d).  Replaces the serial loop over
  * self.models at gpr.py:272-274.  losses: count values; grads: (count, n_theta + m*d) or NULL.
- * Exact models (m = 0, d <= 64) with count > 1 run every stage -- kernel build, Cholesky, solves, L^-1, K^-1, the
- * trace pass -- once for all cells (batched launches, as gprx_factorize_batch); the values are bit-identical to
- * gprx_objective on each cell.  There a cell whose matrix is not positive definite gets NaN loss and gradient and the
- * call returns GPRX_ENOTPD after finishing the others.  Sparse models are evaluated one after the other and the first
- * failure is returned. */
+ * With count > 1 (and d <= 64) every stage runs once for all cells, the cell index in every launch's grid: exact models
+ * -- kernel build, Cholesky, solves, L^-1, K^-1, the trace pass (as gprx_factorize_batch) --, and sparse models -- Kuf,
+ * Kuu, both Cholesky factorisations, A, B (split-K), c, the M x M products of the gradient, both trace passes, dZ: the
+ * ~45 launches of one evaluation serve all cells.  The values are bit-identical to gprx_objective on each cell.  A cell
+ * whose matrix is not positive definite gets NaN loss and gradient and the call returns GPRX_ENOTPD after finishing the
+ * others. */
 int gprx_objective_batch(gprx_handle h, int count, const int* units, const double* theta, const double* z, int mask,
                          double* losses, double* grads);
 

@@ -161,3 +161,24 @@ def test_lockstep_fit_on_the_engine_equals_the_serial_loop():
     ref.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=8)
     for ma, mr in zip(a.models, ref.models):
         assert ma.training_loss() == pytest.approx(mr.training_loss(), rel=1e-6)
+
+
+def test_lockstep_fit_of_sparse_models_on_the_engine():
+    """The reference's default configuration (SGPR, kmeans, two-stage Adam) over 6 modes: lock step with batched
+    evaluations against the serial loop (bit-identical) and the oracle's serial restatement."""
+    x, y = make_hydrograph_features(300, 4, n_outputs=6, config=1, unit=3)
+    xs = x[::7] + 0.01
+    a = GPRAS("Matern32")
+    a.fit(x, y, n_inducing=20, inducing_initializer="kmeans", optimization_method="two-stage", max_iter=12)
+    assert a.lockstep_stats["batches"] < a.lockstep_stats["evaluations"]
+    b = GPRAS("Matern32")
+    b.fit(x, y, n_inducing=20, inducing_initializer="kmeans", optimization_method="two-stage", max_iter=12, lockstep=False)
+    for ma, mb in zip(a.models, b.models):
+        assert ma.variance == mb.variance and ma.noise == mb.noise and ma.lengthscales == mb.lengthscales
+        assert np.array_equal(ma.Z, mb.Z)
+    ref = gpras_oracle.GPRASOracle("Matern32")
+    ref.fit(x, y, n_inducing=20, inducing_initializer="kmeans", optimization_method="two-stage", max_iter=12)
+    mean, var = a.predict(xs)
+    rmean, rvar = ref.predict(xs)
+    assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean))
+    assert np.max(np.abs(var - rvar) / rvar) <= 1e-8

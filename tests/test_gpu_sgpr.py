@@ -139,3 +139,48 @@ def test_golden_vectors_on_gpu(lib, kernel, tag):
         assert np.max(np.abs(var - gold[key + "_var"]) / gold[key + "_var"]) <= 1e-8
     finally:
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("kernel,n,d,m,ard,cells", [("RBF", 500, 4, 30, False, 5), ("Matern32", 700, 6, 70, True, 3), ("Exponential", 300, 3, 64, False, 26), ("Matern52", 4200, 5, 50, False, 4)])
+def test_sparse_objective_batch_equals_single_calls(lib, kernel, n, d, m, ard, cells):
+    """Batched SGPR loss + gradient (theta and Z): every kernel once for all cells -- bit-identical to gprx_objective per
+    cell, 1e-9 / 1e-7 against the oracle; also loss only and a partial mask."""
+    import ctypes as C
+
+    from gpras_amd import _lib
+    from gpras_amd._lib import check, ptr
+    from oracle import kernels as okn
+    from oracle import sgpr as osg
+
+    x, y, _ = make_regression(n, d, n_outputs=3, n_test=0, config=14, unit=n + m)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, m, okn.KERNEL_IDS[kernel], int(ard), C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 3), h)
+    nt = 2 + (d if ard else 1)
+    try:
+        rng = np.random.default_rng(9)
+        units = np.ascontiguousarray(rng.integers(0, 3, size=cells), dtype=np.int32)
+        thetas = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, nt)))
+        zs = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] + 1e-3 * rng.standard_normal((m, d)) for _ in range(cells)]))
+        losses, grads = np.zeros(cells), np.zeros((cells, nt + m * d))
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), ptr(zs), 15, ptr(losses), ptr(grads)), h)
+        for c in range(cells):
+            th, zc = np.ascontiguousarray(thetas[c]), np.ascontiguousarray(zs[c])
+            single, g1 = C.c_double(), np.zeros(nt + m * d)
+            check(lib.gprx_objective(h, int(units[c]), ptr(th), ptr(zc), 15, C.byref(single), ptr(g1)), h)
+            assert single.value == losses[c]
+            assert np.array_equal(g1, grads[c])
+            if c < 3:
+                wl = th[1:-1] if ard else float(th[1])
+                ref_loss, g = osg.loss_and_grad(kernel, x, y[:, units[c]], zc, float(th[0]), wl, float(th[-1]))
+                ref = np.concatenate([[g["variance"]], np.atleast_1d(g["lengthscales"]), [g["noise"]], np.asarray(g["Z"]).ravel()])
+                assert abs(losses[c] - ref_loss) <= 1e-9 * abs(ref_loss)
+                assert np.max(np.abs(grads[c] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref)))
+        l2 = np.zeros(cells)
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), ptr(zs), _lib.TRAIN_Z, ptr(l2), None), h)
+        for c in range(cells):
+            single = C.c_double()
+            check(lib.gprx_factorize(h, int(units[c]), ptr(np.ascontiguousarray(thetas[c])), ptr(np.ascontiguousarray(zs[c])), _lib.TRAIN_Z, C.byref(single)), h)
+            assert single.value == l2[c]
+    finally:
+        lib.gprx_destroy(h)

@@ -186,9 +186,10 @@ class BatchedOracleBackend(OracleBackend):
         super().__init__(*a, **k)
         self.batch_sizes = []
 
-    def objective_batch(self, units, thetas, mask, want_grad=True):
+    def objective_batch(self, units, thetas, mask, want_grad=True, zs=None):
         self.batch_sizes.append(len(units))
-        out = [self.objective(u, t, None, mask, want_grad) for u, t in zip(units, thetas)]
+        zs = [None] * len(units) if zs is None else zs
+        out = [self.objective(u, t, z, mask, want_grad) for u, t, z in zip(units, thetas, zs)]
         losses = np.array([o[0] for o in out])
         grads = np.stack([o[1] for o in out]) if want_grad else None
         return losses, grads, np.isfinite(losses)
@@ -211,6 +212,20 @@ def test_lockstep_fit_equals_serial_loop(monkeypatch, method, kwargs):
         assert ma.n_evals == mb.n_evals and ma.backend is a.engine
 
 
+def test_lockstep_fit_of_sparse_models_equals_serial_loop(monkeypatch):
+    """The reference's default path (SGPR, two-stage Adam): lock step over the modes, Z and hyperparameters per mode."""
+    x, y, _ = make_regression(70, 3, n_outputs=3, n_test=0, config=8, unit=5)
+    monkeypatch.setattr(gpr, "Engine", BatchedOracleBackend)
+    a = gpr.GPRAS("RBF")
+    a.fit(x, y, 7, "grid", "two-stage", max_iter=4)
+    assert max(a.engine.batch_sizes) == 3 and a.lockstep_stats["evaluations"] == sum(m.n_evals for m in a.models)
+    b = gpr.GPRAS("RBF")
+    b.fit(x, y, 7, "grid", "two-stage", max_iter=4, lockstep=False)
+    for ma, mb in zip(a.models, b.models):
+        assert ma.variance == mb.variance and ma.noise == mb.noise and ma.lengthscales == mb.lengthscales
+        assert np.array_equal(ma.Z, mb.Z)
+
+
 def test_lockstep_propagates_failures_without_deadlock(monkeypatch):
     class Failing(BatchedOracleBackend):
         def objective(self, unit, theta, z, mask, want_grad=True):
@@ -218,7 +233,7 @@ def test_lockstep_propagates_failures_without_deadlock(monkeypatch):
                 raise np.linalg.LinAlgError("unit 2 fails")
             return super().objective(unit, theta, z, mask, want_grad)
 
-        def objective_batch(self, units, thetas, mask, want_grad=True):
+        def objective_batch(self, units, thetas, mask, want_grad=True, zs=None):
             losses, grads = [], []
             for u, t in zip(units, thetas):
                 if u == 2:
