@@ -22,7 +22,7 @@ from numpy.typing import NDArray
 from ._lib import KERNEL_IDS
 from .engine import Engine
 from .model import GPModel
-from .optimizers import OPTIMIZERS
+from .optimizers import BATCHED_OPTIMIZERS, OPTIMIZERS
 
 # names that the reference maps to gpflow kernel classes (gpr.py:21-37).  Linear / Polynomial / Periodic
 # are listed there but cannot be constructed with (variance=, lengthscales=) at gpr.py:298 ("currently
@@ -86,6 +86,14 @@ class GPRAS:
         if lockstep and not can_lockstep:
             raise ValueError("lockstep fitting needs several modes on one engine (workers=1)")
         if can_lockstep and (lockstep is None or lockstep):
+            if optimization_method in BATCHED_OPTIMIZERS:
+                # Adam-based drivers: one host loop over all modes (rows of 2-D state arrays), 32 modes per batch
+                before = sum(m.n_evals for m in self.models)
+                stats: dict[str, int] = {"batches": 0}
+                for lo in range(0, len(self.models), 32):
+                    BATCHED_OPTIMIZERS[optimization_method](self.models[lo : lo + 32], stats=stats, **opt_kwargs)
+                self.lockstep_stats = {"batches": stats["batches"], "evaluations": sum(m.n_evals for m in self.models) - before}
+                return
             from .lockstep import fit_lockstep
 
             self.lockstep_stats = fit_lockstep(self.models, opt, opt_kwargs)

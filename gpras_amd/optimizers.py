@@ -167,6 +167,88 @@ def _optimize_differential_evolutions(
     return result
 
 
+# ---- the same drivers over many modes at once ------------------------------------------------------------------------
+# The Adam-based drivers are simple enough to run for all modes of one engine in ONE host loop: the per-mode state lives
+# in the rows of 2-D arrays (numpy applies the same IEEE operations per element as the per-mode code above, so every
+# mode's trajectory -- including its own early stop -- is bit-identical), and every step is one batched evaluation
+# (Engine.objective_batch).  GPRAS.fit uses them in lock-step mode; the other drivers run under gpras_amd.lockstep.
+def _evaluate_many(models, want_grad: bool = True, stats: dict | None = None):
+    if stats is not None:
+        stats["batches"] = stats.get("batches", 0) + 1
+    eng = models[0].backend
+    mask = models[0].mask
+    if any(m.mask != mask for m in models):
+        raise ValueError("all models of a batched step must share the trainable mask")
+    if len(models) == 1:
+        loss, grad = eng.objective(models[0].unit, models[0].theta(), models[0].Z, mask, want_grad=want_grad)
+        losses, grads = np.array([loss]), (None if grad is None else grad[None, :])
+    else:
+        units = [m.unit for m in models]
+        thetas = np.stack([m.theta() for m in models])
+        if models[0].Z is None:
+            losses, grads, ok = eng.objective_batch(units, thetas, mask, want_grad=want_grad)
+        else:
+            losses, grads, ok = eng.objective_batch(units, thetas, mask, want_grad=want_grad, zs=np.stack([m.Z for m in models]))
+        if not ok.all():
+            raise np.linalg.LinAlgError(f"kernel matrix not positive definite for unit(s) {[units[i] for i in np.flatnonzero(~ok)]}")
+    for m in models:
+        m.n_evals += 1
+    packed = None if grads is None else [m._pack_grad(g) for m, g in zip(models, grads)]
+    return losses, packed
+
+
+def _optimize_adam_many(models, max_iter: int, stats: dict | None = None) -> None:
+    """``_optimize_adam`` for every model, one batched evaluation per step (same constants, same early stop per model)."""
+    lr, beta1, beta2, eps = 1e-3, 0.9, 0.999, 1e-7
+    x = np.stack([m.get_vector() for m in models])
+    if x.shape[1] == 0:
+        return
+    mom = np.zeros_like(x)
+    v = np.zeros_like(x)
+    best = np.full(len(models), np.inf)
+    count = np.zeros(len(models), dtype=int)
+    active = np.ones(len(models), dtype=bool)
+    tol = 10e-6
+    patience = 50
+    for t in range(1, int(max_iter) + 1):
+        idx = np.flatnonzero(active)
+        if idx.size == 0:
+            break
+        losses, grads = _evaluate_many([models[i] for i in idx], stats=stats)
+        g = np.stack(grads)
+        mom[idx] = beta1 * mom[idx] + (1.0 - beta1) * g
+        v[idx] = beta2 * v[idx] + (1.0 - beta2) * g * g
+        alpha = lr * np.sqrt(1.0 - beta2**t) / (1.0 - beta1**t)
+        x[idx] = x[idx] - alpha * mom[idx] / (np.sqrt(v[idx]) + eps)
+        for j, i in enumerate(idx):
+            models[i].set_vector(x[i])
+            loss = losses[j]
+            if ((best[i] - loss) / abs(loss)) > tol:
+                best[i] = loss
+                count[i] = 0
+            else:
+                count[i] += 1
+                if count[i] > patience:
+                    active[i] = False
+
+
+def _optimize_two_stage_many(models, max_iter: int = 100, stats: dict | None = None) -> None:
+    """``_optimize_two_stage`` for every model (gpr.py:112-127)."""
+    for m in models:
+        m.set_all_trainable(False)
+        m.set_trainable(Z=True)
+    _optimize_adam_many(models, max_iter, stats)
+    for m in models:
+        m.set_all_trainable(True)
+        m.set_trainable(Z=False)
+    _optimize_adam_many(models, max_iter, stats)
+    for m in models:
+        m.set_trainable(Z=True)
+    _evaluate_many(models, want_grad=False, stats=stats)  # the final training_loss() of the reference's driver
+
+
+BATCHED_OPTIMIZERS: dict[str, Any] = {"adam": _optimize_adam_many, "two-stage": _optimize_two_stage_many}
+
 OPTIMIZERS: dict[str, Any] = {
     "two-stage": _optimize_two_stage,
     "three-stage": _optimize_three_stage,
