@@ -82,30 +82,36 @@ class GPRAS:
         self.y = y.astype(np.float64)
         opt = OPTIMIZERS[optimization_method]  # KeyError before any device work, as the reference (gpr.py:272)
         self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard, workers=workers)
-        can_lockstep = len(self.models) > 1 and len(self.engines) == 1 and hasattr(self.engine, "objective_batch")
+        self._run_optimizers(self.models, optimization_method, lockstep, opt_kwargs)
+
+    def _run_optimizers(self, models: list[GPModel], optimization_method: str, lockstep: bool | None, opt_kwargs: dict[str, Any]) -> None:
+        """The per-mode loop of gpr.py:272-274 over ``models`` (all of them, or one rank's share): in lock step on
+        batched evaluations where possible, else serially, else from ``workers`` host threads."""
+        opt = OPTIMIZERS[optimization_method]
+        can_lockstep = len(models) > 1 and len(self.engines) == 1 and hasattr(self.engine, "objective_batch")
         if lockstep and not can_lockstep:
             raise ValueError("lockstep fitting needs several modes on one engine (workers=1)")
         if can_lockstep and (lockstep is None or lockstep):
             if optimization_method in BATCHED_OPTIMIZERS:
                 # Adam-based drivers: one host loop over all modes (rows of 2-D state arrays), 32 modes per batch
-                before = sum(m.n_evals for m in self.models)
+                before = sum(m.n_evals for m in models)
                 stats: dict[str, int] = {"batches": 0}
-                for lo in range(0, len(self.models), 32):
-                    BATCHED_OPTIMIZERS[optimization_method](self.models[lo : lo + 32], stats=stats, **opt_kwargs)
-                self.lockstep_stats = {"batches": stats["batches"], "evaluations": sum(m.n_evals for m in self.models) - before}
+                for lo in range(0, len(models), 32):
+                    BATCHED_OPTIMIZERS[optimization_method](models[lo : lo + 32], stats=stats, **opt_kwargs)
+                self.lockstep_stats = {"batches": stats["batches"], "evaluations": sum(m.n_evals for m in models) - before}
                 return
             from .lockstep import fit_lockstep
 
-            self.lockstep_stats = fit_lockstep(self.models, opt, opt_kwargs)
+            self.lockstep_stats = fit_lockstep(models, opt, opt_kwargs)
             return
         if len(self.engines) == 1:
-            for _, model in enumerate(self.models):
+            for model in models:
                 opt(model, **opt_kwargs)
             return
         from concurrent.futures import ThreadPoolExecutor
 
         def run(worker: int) -> None:
-            for model in self.models[worker :: len(self.engines)]:
+            for model in models[worker :: len(self.engines)]:
                 opt(model, **opt_kwargs)
 
         with ThreadPoolExecutor(max_workers=len(self.engines)) as pool:

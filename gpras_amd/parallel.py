@@ -75,14 +75,17 @@ class ShardedGPRAS(GPRAS):
             out[row] = np.concatenate([[m.w_var], m.w_len, [m.w_noise], z])
         return out
 
-    def fit(self, x, y, n_inducing, inducing_initializer="kmeans", optimization_method="two-stage", ard: bool = False, **opt_kwargs: Any) -> None:
+    def fit(
+        self, x, y, n_inducing, inducing_initializer="kmeans", optimization_method="two-stage", ard: bool = False, lockstep: bool | None = None,
+        **opt_kwargs: Any,
+    ) -> None:
         self.x = x.astype(np.float64)
         self.y = y.astype(np.float64)
-        opt = OPTIMIZERS[optimization_method]
+        OPTIMIZERS[optimization_method]  # KeyError before any device work, as the reference
         self._init_models(self.x, self.y, n_inducing, inducing_initializer, ard)
         mine = shard_units(len(self.models), self.rank, self.world)
-        for u in mine:
-            opt(self.models[u], **opt_kwargs)
+        # this rank's modes: in lock step on batched evaluations (as GPRAS.fit), no communication
+        self._run_optimizers([self.models[u] for u in mine], optimization_method, lockstep, opt_kwargs)
         # the single collective of fit: everyone learns everyone's parameters
         n_len = self.engine.n_len
         zsize = 0 if self.models[0].Z is None else self.models[0].Z.size
