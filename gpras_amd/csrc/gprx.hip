@@ -119,6 +119,11 @@ int fail(gprx_handle h, int code, const std::string& msg) {
     }                                                                                              \
   } while (0)
 
+int& predict_path_tuning() {
+  static int v = 0;  // 0: choose, 1: always through L^-1, 2: always forward substitution
+  return v;
+}
+
 int ensure(gprx_handle h, Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return GPRX_OK;
   if (b.p && !b.borrowed) HIPCHK(h, hipFree(b.p));
@@ -1468,7 +1473,11 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   // Many test points: V = L^-1 Ks as ONE triangular GEMM per tile against the explicit inverse (computed once
   // per factorisation, N^3/3 flops amortised over N* >= 2 N points) instead of the recursive solve's ~2 N/64
   // dependent launches per tile.  Few points: blocked forward substitution on L itself.
-  const bool use_inverse = ns >= 2 * (int64_t)h->n;
+  // Measured at N = 4096 (tools/predict_sizes.py): the substitution path costs ~1.7 ms whatever the batch (2 N / 64
+  // dependent launches), the inverse path 0.9 ms for L^-1 plus 0.3 us per point -- faster for every batch size; at larger
+  // N the N^3 / 3 flops of L^-1 only pay from about N / 2 points on.  predict_path (gprx_set_tuning): 1 / 2 force a path.
+  const int forced = predict_path_tuning();
+  const bool use_inverse = forced == 1 || (forced != 2 && (h->have_linv || h->n <= 4096 || 2 * ns >= (int64_t)h->n));
   if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile * (use_inverse ? 2 : 1)))) return rc;
   double* Vbuf = h->Ks.p + (use_inverse ? (size_t)h->np * tile : 0);
   if (use_inverse && !h->have_linv) {
@@ -1908,6 +1917,7 @@ int gprx_set_tuning(const char* key, int value) {
   else if (k == "panel_occ" && (value == 0 || value == 2 || value == 3)) t.panel_occ = value;
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
+  else if (k == "predict_path" && value >= 0 && value <= 2) predict_path_tuning() = value;
   else return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
   return GPRX_OK;
 }

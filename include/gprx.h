@@ -232,7 +232,8 @@ int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const
  * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
  * "inblock" (1: right-looking K = 64 strips inside an outer block instead of recursive halving), "split_panel"
  * (1: always one diagonal workgroup + a rows-only kernel per panel, -1: never; default: from 24 cells per launch on).
- * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical. */
+ * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical.
+ * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution. */
 int gprx_set_tuning(const char* key, int value);
 
 /* measured back-to-back v_mfma_f64_16x16x4_f64 rate of the whole chip, TFLOP/s */

@@ -207,3 +207,26 @@ def test_full_size_16384_gradient_matches_central_differences(lib):
         assert np.all(var <= 2.0 * noise + 1e-9)  # at a training point the latent variance is below the noise
     finally:
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_both_predict_paths_agree_with_the_oracle(lib, path):
+    """The exact predict has two routes to V = L^-1 Ks (triangular GEMM against the explicit inverse, blocked forward
+    substitution); the default choice depends on N and the batch, so each is forced here."""
+    n, d, ns = 700, 5, 333
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=ns, config=15, unit=path)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["Matern32"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    try:
+        check(lib.gprx_set_tuning(b"predict_path", path))
+        theta = theta_of(1.2, 0.8, 0.03)
+        loss = C.c_double()
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss)), h)
+        mean, var = np.zeros(ns), np.zeros(ns)
+        check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(var), 1), h)
+        rm, rv = oex.predict("Matern32", x, y[:, 0], 1.2, 0.8, 0.03, xs)
+        assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
+    finally:
+        lib.gprx_set_tuning(b"predict_path", 0)
+        lib.gprx_destroy(h)
