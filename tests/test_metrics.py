@@ -93,3 +93,37 @@ def test_gpu_metrics_nan_peaks_and_errors():
         gm.FieldMetrics(x, y[:, :-1])
     with pytest.raises(ValueError):
         gm.FieldMetrics(x, y, t_tol=9)
+
+
+def _golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fields_golden.npz"))
+
+
+def _scalars(mod_or_obj, x, y):
+    f = mod_or_obj
+    return np.array([f.rmse_aoi_toi(x, y), f.mae_aoi_toi(x, y), f.err_aoi_toi(x, y), f.rmse_aoi_mts(x, y), f.nse_aoi_mts(x, y), f.err_aoi_mts(x, y),
+                     f.fi_aoi_toi(x, y, 2, 0.04), f.pod_mts(x, y, 101.0), f.rfa_mts(x, y, 101.0), f.csi_mts(x, y, 101.0), f.f2_mts(x, y, 101.0),
+                     f.f3_mts(x, y, 101.0)])
+
+
+def test_oracle_reproduces_golden_metrics():
+    g = _golden()
+    x, y = g["wse_full"], g["met_y"]
+    np.testing.assert_allclose(_scalars(om, x, y), g["met_scalars"], rtol=1e-13)
+    assert np.array_equal(np.argmax(x, axis=0), g["met_x_mts"]) and np.array_equal(np.argmax(y, axis=0), g["met_y_mts"])
+
+
+@pytest.mark.gpu
+def test_gpu_metrics_reproduce_golden():
+    from gpras_amd import metrics as gm
+
+    g = _golden()
+    x, y = np.ascontiguousarray(g["wse_full"]), np.ascontiguousarray(g["met_y"])
+    np.testing.assert_allclose(_scalars(gm, x, y), g["met_scalars"], rtol=1e-10)
+    fm = gm.FieldMetrics(x, y)
+    assert np.array_equal(fm.x_mts, g["met_x_mts"]) and np.array_equal(fm.y_mts, g["met_y_mts"])
+    np.testing.assert_allclose(fm.rmse_aoi_ts(), g["met_rmse_ts"], rtol=1e-12)
+    np.testing.assert_allclose(fm.rmse_cell_toi(), g["met_rmse_cell"], rtol=1e-12)
+    assert np.array_equal(fm.err_cell_mts(), g["met_err_cell_mts"])

@@ -119,3 +119,34 @@ def test_gpu_projection_chunked_rows_and_errors(monkeypatch):
     p = EOFProjector(st["dry"], st["elevations"], m, st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse")
     with pytest.raises(ValueError):
         p.transform(st["x"][:, :-1])
+
+
+def _golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fields_golden.npz"))
+
+
+@pytest.mark.parametrize("mode", ["wse", "depth"])
+def test_oracle_reproduces_golden_fields(mode):
+    g = _golden()
+    args = (g["dry"], g["elevations"], g[f"{mode}_input_mean"], g["weights"], g["eofs"], g["x_mean"], g["x_std"], mode)
+    z = opca.transform(g["x"], *args)
+    np.testing.assert_allclose(z, g[f"{mode}_z"], rtol=0, atol=1e-13 * np.abs(g[f"{mode}_z"]).max())
+    full, vfull = opca.reverse_transform(g[f"{mode}_z"], 0.01 + 0.1 * np.abs(g[f"{mode}_z"]), *args)
+    np.testing.assert_allclose(full, g[f"{mode}_full"], rtol=1e-14)
+    np.testing.assert_allclose(vfull, g[f"{mode}_vfull"], rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["wse", "depth"])
+def test_gpu_projection_reproduces_golden_fields(mode):
+    from gpras_amd.preprocess import EOFProjector
+
+    g = _golden()
+    p = EOFProjector(g["dry"], g["elevations"], g[f"{mode}_input_mean"], g["weights"], g["eofs"], g["x_mean"], g["x_std"], mode)
+    z = p.transform(g["x"])
+    assert np.max(np.abs(z - g[f"{mode}_z"])) <= 1e-11 * np.max(np.abs(g[f"{mode}_z"]))
+    full, vfull = p.reverse_transform(g[f"{mode}_z"], 0.01 + 0.1 * np.abs(g[f"{mode}_z"]))
+    assert np.max(np.abs(full - g[f"{mode}_full"])) <= 1e-13 * np.max(np.abs(g[f"{mode}_full"]))
+    assert np.max(np.abs(vfull - g[f"{mode}_vfull"])) <= 1e-13 * np.max(np.abs(g[f"{mode}_vfull"]))
