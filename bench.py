@@ -252,6 +252,15 @@ def main():
         extra["predict_points_per_s"] = N_TEST / tp
         extra["predict_tflops"] = (N_TRAIN**2 * N_TEST + 2.0 * N_TRAIN * N_TEST) / tp / 1e12
         extra["predict_n_test"] = N_TEST
+        # BASELINE configs[3] per GPU: independent cells, each fitted (batched) and predicted at the shared 100k test points
+        # (gprx_predict_batch: host buffers in and out, i.e. PCIe-inclusive)
+        c4 = 4
+        pm, pv = np.zeros((c4, N_TEST)), np.zeros((c4, N_TEST))
+        t1 = time.perf_counter()
+        check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), N_TEST, ptr(pm), ptr(pv), 1), h)
+        tc4 = time.perf_counter() - t1
+        extra["C4_fit_plus_predict_100k_cells_per_s"] = c4 / tc4
+        extra["C4_seconds_for_10k_cells_on_8_gpus_extrapolated"] = 10000 / 8 / (c4 / tc4)
         gpu_mean = dmean.to_array((N_TEST,))[:2000]
         gpu_var = dvar.to_array((N_TEST,))[:2000]
         # F3: BASELINE configs[2] -- Matern-5/2 ARD, 50 L-BFGS-B iterations on the exact LML
