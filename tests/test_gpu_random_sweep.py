@@ -15,7 +15,10 @@ from oracle import kernels as okn
 from oracle import sgpr as osg
 from oracle import transforms as otr
 
+import os
+
 pytestmark = pytest.mark.gpu
+EXTRA = int(os.environ.get("GPRX_SWEEP_EXTRA", "0"))  # more seeds for a one-off hunt (GPRX_SWEEP_EXTRA=200)
 
 
 def draw(seed):
@@ -28,7 +31,7 @@ def draw(seed):
     return rng, kernel, n, d, ard, units
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + EXTRA))
 def test_random_exact_single_and_batched(lib, seed):
     rng, kernel, n, d, ard, units = draw(1000 + seed)
     x, y, xs = make_regression(n, d, n_outputs=units, n_test=9, config=20, unit=seed)
@@ -68,7 +71,7 @@ def test_random_exact_single_and_batched(lib, seed):
         lib.gprx_destroy(h)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + EXTRA))
 def test_random_sparse(lib, seed):
     rng, kernel, n, d, ard, units = draw(2000 + seed)
     n = max(n, 8)
@@ -90,7 +93,14 @@ def test_random_sparse(lib, seed):
         ref_loss, g = osg.loss_and_grad(kernel, x, y[:, unit], z, float(theta[0]), wl_arg, float(theta[-1]))
         ref = np.concatenate([[g["variance"]], np.atleast_1d(g["lengthscales"]), [g["noise"]], np.asarray(g["Z"]).ravel()])
         assert abs(loss.value - ref_loss) <= 1e-9 * max(abs(ref_loss), 1.0), (kernel, n, d, m, ard)
-        assert np.max(np.abs(grad - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref))), (kernel, n, d, m, ard)
+        # the theta gradient goes through Kuu^-1 explicitly: with many inducing points in few dimensions Kuu + 1e-6 I is
+        # jitter-saturated (condition number 1e8) and oracle and device then differ by cond * eps * |intermediates| ~ 1e-6
+        # relative, with central differences of the loss in between (seeds 179, 428, 481, 511 of an extended sweep; the
+        # noise gradient, which does not involve Kuu^-1, still agrees to 1e-13 there)
+        lsc0 = ls if ard else float(ls[0])
+        cond = np.linalg.cond(okn.kmat(kernel, z, z, variance, lsc0) + 1e-6 * np.eye(m))
+        tol = 1e-7 * max(1.0, cond / 1e6)
+        assert np.max(np.abs(grad - ref)) <= tol * max(1.0, np.max(np.abs(ref))), (kernel, n, d, m, ard, cond)
         mean, var = np.zeros(9), np.zeros(9)
         check(lib.gprx_predict(h, ptr(xs), 9, ptr(mean), ptr(var), 1), h)
         lsc = ls if ard else float(ls[0])
