@@ -127,3 +127,25 @@ def test_gpu_metrics_reproduce_golden():
     np.testing.assert_allclose(fm.rmse_aoi_ts(), g["met_rmse_ts"], rtol=1e-12)
     np.testing.assert_allclose(fm.rmse_cell_toi(), g["met_rmse_cell"], rtol=1e-12)
     assert np.array_equal(fm.err_cell_mts(), g["met_err_cell_mts"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_metrics_random_shapes(seed):
+    from gpras_amd import metrics as gm
+
+    rng = np.random.default_rng(500 + seed)
+    t = int(rng.choice([1, 2, 3, 9, 10, 40]))
+    cells = int(rng.choice([1, 2, 255, 256, 257, rng.integers(300, 4000)]))
+    t_tol = int(rng.integers(0, 9))
+    v_tol = float(rng.choice([0.0, 0.05, 0.5]))
+    x, y, conf = fields(t, cells, 600 + seed, ties=bool(rng.integers(2)) and t >= 3 and cells >= 12)
+    fm = gm.FieldMetrics(x, y, conf, t_tol=t_tol, v_tol=v_tol)
+    assert np.array_equal(fm.x_mts, np.argmax(x, axis=0)) and np.array_equal(fm.y_mts, np.argmax(y, axis=0)), (t, cells)
+    assert fm.fi_aoi_toi() == om.fi_aoi_toi(x, y, t_tol, v_tol), (t, cells, t_tol, v_tol)
+    assert tuple(int(v) for v in fm.contingency(0.5)) == tuple(int(v) for v in om.contingency(x, y, 0.5))
+    assert fm.rmse_aoi_toi() == pytest.approx(om.rmse_aoi_toi(x, y), rel=1e-12)
+    np.testing.assert_allclose(fm.rmse_aoi_ts(), om.rmse_aoi_ts(x, y), rtol=1e-12)
+    np.testing.assert_allclose(fm.rmse_cell_toi(), om.rmse_cell_toi(x, y), rtol=1e-12)
+    np.testing.assert_allclose(fm.conf_cell_toi(), om.conf_cell_toi(conf), rtol=1e-12)
+    np.testing.assert_allclose(fm.conf_aoi_ts(), om.conf_aoi_ts(conf), rtol=1e-12)

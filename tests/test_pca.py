@@ -150,3 +150,40 @@ def test_gpu_projection_reproduces_golden_fields(mode):
     full, vfull = p.reverse_transform(g[f"{mode}_z"], 0.01 + 0.1 * np.abs(g[f"{mode}_z"]))
     assert np.max(np.abs(full - g[f"{mode}_full"])) <= 1e-13 * np.max(np.abs(g[f"{mode}_full"]))
     assert np.max(np.abs(vfull - g[f"{mode}_vfull"])) <= 1e-13 * np.max(np.abs(g[f"{mode}_vfull"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_projection_random_shapes(seed):
+    """Random shapes around the edges: very few cells, k up to the 64-mode limit, one row, no dry cells, no weights."""
+    from gpras_amd.preprocess import EOFProjector
+
+    rng = np.random.default_rng(300 + seed)
+    n_cells = int(rng.choice([rng.integers(3, 40), rng.integers(40, 600), rng.integers(600, 5000)]))
+    mode = ["wse", "depth", "velocity"][seed % 3]
+    weighted = bool(rng.integers(2))
+    st = make_eof_state(n_cells, 1, 3, 400 + seed, dry_fraction=float(rng.choice([0.0, 0.2, 0.6])), weighted=weighted)
+    n_wet = int((~st["dry"]).sum())
+    if n_wet == 0:
+        st["dry"][0] = False
+        n_wet = 1
+    k = int(min(n_wet, rng.choice([1, 2, 16, 17, 33, 64])))
+    t = int(rng.choice([1, 2, 31, 64, 65]))
+    q, _ = np.linalg.qr(rng.standard_normal((n_wet, k)))
+    eofs = np.ascontiguousarray(q.T)
+    x = st["elevations"] + rng.standard_normal((t, n_cells))
+    field = opca.wse_2_depth(x.copy(), st["elevations"]) if mode == "depth" else x
+    mu = field[:, ~st["dry"]].mean(axis=0)
+    w = (0.5 + rng.random(n_wet)) if weighted else None
+    xm, xs_ = rng.standard_normal(k), 0.5 + rng.random(k)
+    args = (st["dry"], st["elevations"], mu, w, eofs, xm, xs_, mode)
+    p = EOFProjector(st["dry"], st["elevations"], mu, w, eofs, xm, xs_, mode)
+    z = p.transform(x)
+    zr = opca.transform(x, *args)
+    assert np.max(np.abs(z - zr)) <= 1e-11 * max(np.max(np.abs(zr)), 1e-3), (n_cells, k, t, mode)
+    var = rng.random((t, k))
+    full, vfull = p.reverse_transform(zr, var)
+    fr, vr = opca.reverse_transform(zr, var, *args)
+    assert np.max(np.abs(full - fr)) <= 1e-13 * np.max(np.abs(fr)), (n_cells, k, t, mode)
+    assert np.max(np.abs(vfull - vr)) <= 1e-13 * max(np.max(np.abs(vr)), 1e-300), (n_cells, k, t, mode)
+    p.close()
