@@ -471,16 +471,27 @@ __global__ __launch_bounds__(256) void syrk_k64_kernel(const double* __restrict_
         acc[a][b][q] = (row < M && col < N) ? C[(int64_t)row * ldc + col] : 0.0;
       }
     }
+  // LDS image: inside every block of 16 k the elements are stored 4 x 4 transposed (k_local -> (k_local % 4) * 4 +
+  // k_local / 4), so that the four consecutive doubles lane group g reads for a step are k = 16 ks + {g, 4 + g, 8 + g,
+  // 12 + g}: MFMA j of a step then sums the four CONSECUTIVE k = 16 ks + 4 j + {0..3}, and the 16 MFMAs of a tile walk k
+  // in ascending groups of four -- the same order in which the 8-column sub-panel updates of the panel kernels reach an
+  // element, which is what keeps 64- and 128-column panels bit-identical.
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int q = tid + 256 * i;
     const int row = q >> 5, cc = q & 31;
-    *reinterpret_cast<d2*>(sA + row * S64_LD + 2 * (cc ^ (row & 15))) = ra[i];
-    *reinterpret_cast<d2*>(sB + row * S64_LD + 2 * (cc ^ (row & 15))) = rb[i];
+    const int c8 = cc & 7;
+    const int pos0 = 16 * (cc >> 3) + 8 * (c8 & 1) + (c8 >> 1), pos1 = pos0 + 4;
+    const int sw = row & 15;
+    const int o0 = 2 * ((pos0 >> 1) ^ sw) + (pos0 & 1), o1 = 2 * ((pos1 >> 1) ^ sw) + (pos1 & 1);
+    sA[row * S64_LD + o0] = ra[i].x;
+    sA[row * S64_LD + o1] = ra[i].y;
+    sB[row * S64_LD + o0] = rb[i].x;
+    sB[row * S64_LD + o1] = rb[i].y;
   }
   __syncthreads();
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {  // 16 k per step; lane group g takes k = 16 ks + 4 g + j
+  for (int ks = 0; ks < 4; ++ks) {  // 16 k per step; MFMA j of the step takes k = 16 ks + 4 j + (lane group)
     double fa[2][4], fb[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {

@@ -229,7 +229,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if ((rc = ensure(h, h->Kmat, sizeof(double) * (h->np + NB) * ld))) return rc;
   if ((rc = ensure(h, h->invD, sizeof(double) * h->np * NB))) return rc;
   if ((rc = ensure(h, h->alpha, sizeof(double) * h->np))) return rc;
-  if ((rc = ensure(h, h->dstage, sizeof(double) * h->np * PW))) return rc;
+  if ((rc = ensure(h, h->dstage, sizeof(double) * h->np * STAGE_LD))) return rc;
   if (lookahead && (rc = ensure_lookahead(h))) return rc;
   hipStream_t st = h->stream;
   if (capture) {
@@ -411,7 +411,7 @@ int ensure_arena(gprx_handle h, int slots) {
   const int64_t np = h->np;
   h->off_invd = (np + NB) * np;
   h->off_stage = h->off_invd + np * NB;
-  h->off_alpha = h->off_stage + np * PW;
+  h->off_alpha = h->off_stage + np * STAGE_LD;
   h->cell_stride = round_up(h->off_alpha + np, 64);
   for (Buf* b : {&h->arena, &h->cellpar, &h->cellres}) {
     if (b->p) HIPCHK(h, hipFree(b->p));
@@ -672,7 +672,7 @@ int sgpr_alloc(gprx_handle h) {
   if ((rc = ensure(h, h->invDL, sizeof(double) * mp * NB))) return rc;
   if ((rc = ensure(h, h->invDB, sizeof(double) * mp * NB))) return rc;
   if ((rc = ensure_zeroed(h, h->vecs, sizeof(double) * (4 * mp + np)))) return rc;
-  if ((rc = ensure(h, h->dstage, sizeof(double) * std::max(mp, np) * PW))) return rc;
+  if ((rc = ensure(h, h->dstage, sizeof(double) * std::max(mp, np) * STAGE_LD))) return rc;
   // split-K slabs: K = np in slices of SPLITK_CHUNK, outputs up to mp x mp
   if ((rc = ensure(h, h->splitws, sizeof(double) * ((np + SPLITK_CHUNK - 1) / SPLITK_CHUNK) * mp * mp))) return rc;
   return GPRX_OK;
@@ -868,7 +868,7 @@ SgprLayout sgpr_batch_layout(gprx_handle h) {
   L.oWHQ = take(mp * mp);
   L.oVecs = take(4 * mp + np);
   L.odZ = take(m * d);
-  L.oStage = take(mp * PW);
+  L.oStage = take(mp * STAGE_LD);
   L.oPart = take(L.part_p + L.part_q + 2 * L.width);
   L.oWs = take((int64_t)L.nsplit * mp * mp);
   L.oRed = take(8);
@@ -1885,7 +1885,7 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   HIPCHK(nullptr, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   HIPCHK(nullptr, ps.init());
   double* dstage = nullptr;
-  HIPCHK(nullptr, hipMalloc((void**)&dstage, sizeof(double) * np * PW));
+  HIPCHK(nullptr, hipMalloc((void**)&dstage, sizeof(double) * np * STAGE_LD));
   hipError_t e = potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
   hipError_t e2 = hipDeviceSynchronize();
   hipFree(dstage);

@@ -454,12 +454,16 @@ __global__ __launch_bounds__(256, 3) void potrf_rows_kernel(double* __restrict__
 // LDS holds only the two 8-column sub-panel buffers (18 KiB); solved values go straight to memory
 // (one thread = one row, 64 contiguous bytes per sub-panel).
 constexpr int PW = 128;
+// staging area: STAGE_LD doubles per matrix column; the panel at column c stages its diagonal block (pw x pw, row-major)
+// at c * STAGE_LD and its pw reciprocal pivots right behind it (64 * 64 + 64 and 128 * 128 + 128 both fit)
+constexpr int STAGE_LD = PW + 1;
 
 struct Panel128Ctx {
   double* sIn;   // [256][9]
   double* sX;    // [256][9]
   double* out;   // this thread's output row in global memory (nullptr: nothing to write)
   double* inv_diag;
+  double* rinv_out;  // last workgroup: the 128 reciprocal pivots behind the staged block (read by potrf_rows128_kernel)
   int tid, wave, g, r;
   int zero_above;
   int ident;     // >= 0: this thread carries identity row `ident` (last workgroup)
@@ -527,6 +531,10 @@ __device__ __forceinline__ void panel128_step(d4 (&acc)[4][8], Panel128Ctx& c, D
     }
   }
   c.bad = bad;
+  if (c.rinv_out && c.tid == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.rinv_out[C0 + j] = rinv[j];
+  }
   double x[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -611,6 +619,7 @@ __global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict_
   c.bad = 0;
   c.inv_diag = inv_diag;
   const bool last = (int)blockIdx.x == nchunks;
+  c.rinv_out = last ? stage_out + PW * PW : nullptr;
   // output row of this thread
   c.out = nullptr;
   c.ident = -1;
@@ -669,6 +678,168 @@ __global__ __launch_bounds__(256) void potrf_panel128_kernel(double* __restrict_
   panel128_step<14>(acc, c, df);
   panel128_step<15>(acc, c, df);
   if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
+}
+
+// ---- split panel, 128 columns: rows only ------------------------------------------------------------------------
+// potrf_panel128_kernel launched with ONE workgroup per cell factors the 128 x 128 diagonal block (staged L11, the two
+// 64 x 64 blocks of L11^-1, 128 reciprocal pivots); this kernel solves the rows below it, 128 rows x 128 columns per
+// workgroup.  It replaces [rows of panel c] + [K = 64 update of columns c + 64 .. c + 127] + [rows of panel c + 64] of
+// the 64-column scheme with ONE pass over the 128 columns (4 instead of 7 column-block transfers per pair, 1-KiB row
+// segments): the update of the second half happens through the 8-column sub-panel updates, which reach an element in the
+// same ascending groups of four k as syrk_k64_kernel does, so the factor is bit-identical to the 64-column paths.
+// L11 is not kept in LDS (128 KiB): the 8-column strip of L11 a step needs (its 8 x 8 diagonal sub-block for the
+// substitution, the rows below it as MFMA operands) is fetched one step ahead into a double-buffered 128 x 8 image.
+constexpr int R128_ROWS = 128;
+
+template <int P>
+__device__ __forceinline__ void rows128_step(d4 (&acc)[2][8], double* __restrict__ sIn, double* __restrict__ sX, double* __restrict__ sS,
+                                             const double* __restrict__ sRinv, const double* __restrict__ stage, int tid, int wave, int g, int r) {
+  constexpr int C0 = 8 * P;
+  constexpr int KT = C0 / 16;
+  constexpr int HALF = P & 1;
+  double* cur = sS + (P & 1) * (PW * PSUB);         // strip of this step: cur[row * PSUB + m] = L11[row][C0 + m]
+  double* nxt = sS + ((P + 1) & 1) * (PW * PSUB);
+  // prefetch the next strip (rows 0..127, columns C0 + 8 .. C0 + 15): 4 doubles per thread
+  d2 pf0 = d2{0.0, 0.0}, pf1 = d2{0.0, 0.0};
+  if constexpr (P < 15) {
+    const int row = tid >> 1, half = tid & 1;
+    const double* src = stage + row * PW + C0 + 8 + 4 * half;
+    pf0 = *reinterpret_cast<const d2*>(src);
+    pf1 = *reinterpret_cast<const d2*>(src + 2);
+  }
+  if ((r >> 3) == HALF) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sIn[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)] = acc[rt][KT][q];
+  }
+  __syncthreads();
+  if (tid < R128_ROWS) {
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double t = sIn[tid * PSUB + k];
+#pragma unroll
+      for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], cur[(C0 + k) * PSUB + m], t);
+      x[k] = t * sRinv[C0 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sX[tid * PSUB + k] = x[k];
+  }
+  __syncthreads();
+  if constexpr (C0 + 8 < PW) {
+    constexpr int KT0 = (C0 + 8) / 16;
+    double fa[2][2], fb[8][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -sX[(32 * wave + 16 * rt + r) * PSUB + 4 * ks + g];
+#pragma unroll
+    for (int kt = KT0; kt < 8; ++kt) {
+      const int kk = kt * 16 + r;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb[kt][ks] = (kk >= C0 + 8) ? cur[kk * PSUB + 4 * ks + g] : 0.0;
+    }
+#pragma unroll
+    for (int kt = KT0; kt < 8; ++kt)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
+        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
+      }
+  }
+  if ((r >> 3) == HALF) {  // solved values back into the accumulators: one coalesced store pass at the end
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = sX[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)];
+  }
+  if constexpr (P < 15) {  // publish the next strip (the other buffer: nobody reads it in this step)
+    const int row = tid >> 1, half = tid & 1;
+    double* dst = nxt + row * PSUB + 4 * half;
+    dst[0] = pf0.x;
+    dst[1] = pf0.y;
+    dst[2] = pf1.x;
+    dst[3] = pf1.y;
+  }
+}
+
+// A21: first row below the 128 x 128 diagonal block (rows_below rows, lda); stage: staged L11 (128 x 128, row-major)
+// followed by the 128 reciprocal pivots.  grid = (ceil(rows_below / 128), cells).
+__global__ __launch_bounds__(256, 2) void potrf_rows128_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
+                                                               const double* __restrict__ stage, int64_t cs) {
+  __shared__ __attribute__((aligned(16))) double sIn[R128_ROWS * PSUB];
+  __shared__ __attribute__((aligned(16))) double sX[R128_ROWS * PSUB];
+  __shared__ __attribute__((aligned(16))) double sS[2 * PW * PSUB];
+  __shared__ double sRinv[PW];
+  A21 += (int64_t)blockIdx.y * cs;
+  stage += (int64_t)blockIdx.y * cs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  const int row0 = blockIdx.x * R128_ROWS;
+  d4 acc[2][8];
+  {
+    const double* rowp[2][4];
+    bool valid[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = row0 + 32 * wave + 16 * rt + g + 4 * q;
+        valid[rt][q] = idx < rows_below;
+        rowp[rt][q] = A21 + (int64_t)(valid[rt][q] ? idx : 0) * lda + r;
+      }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) acc[rt][kt][q] = rowp[rt][q][kt * 16];
+    // first strip (columns 0..7 of L11) and the reciprocal pivots
+    {
+      const int row = tid >> 1, half = tid & 1;
+      const double* src = stage + row * PW + 4 * half;
+      const d2 v0 = *reinterpret_cast<const d2*>(src), v1 = *reinterpret_cast<const d2*>(src + 2);
+      double* dst = sS + row * PSUB + 4 * half;
+      dst[0] = v0.x;
+      dst[1] = v0.y;
+      dst[2] = v1.x;
+      dst[3] = v1.y;
+    }
+    if (tid < PW) sRinv[tid] = stage[PW * PW + tid];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) acc[rt][kt][q] = valid[rt][q] ? acc[rt][kt][q] : 0.0;
+  }
+  rows128_step<0>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<1>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<2>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<3>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<4>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<5>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<6>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<7>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<8>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<9>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<10>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<11>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<12>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<13>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<14>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+  rows128_step<15>(acc, sIn, sX, sS, sRinv, stage, tid, wave, g, r);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = row0 + 32 * wave + 16 * rt + g + 4 * q;
+      if (idx < rows_below) {
+        double* dst = A21 + (int64_t)idx * lda + r;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) dst[kt * 16] = acc[rt][kt][q];
+      }
+    }
 }
 
 // Optional per-launch timing of the two kernels of the factorisation (HIP events on the launch stream).
@@ -759,7 +930,7 @@ struct PotrfStreams {
 //                flops), overlapping the next block's panel chain on the main stream.
 // Order: TAIL(J) waits for HEAD(J) to be enqueued behind block J (event) and follows TAIL(J-1)
 // (stream order); HEAD(J) waits for TAIL(J-1), the last writer of the next block's columns.
-// diag_stage: scratch of np * 128 doubles (staged diagonal blocks, see potrf_panel_kernel)
+// diag_stage: scratch of np * STAGE_LD doubles (staged diagonal blocks and reciprocal pivots, see potrf_panel_kernel)
 // batch > 1: `batch` matrices at A + c * cs (inv_diag and diag_stage likewise: all live in cell blocks `cs` doubles apart),
 // info words info_stride ints apart; every launch carries the cell index in blockIdx.y.
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
@@ -782,6 +953,10 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   const PotrfTuning& tune = potrf_tuning();
   if (tune.no_lookahead) ps = nullptr;
   const int ob = tune.outer_block ? tune.outer_block : (np > 4096 ? 512 : 1024);  // measured: N=2048/4096 -> 1024, N=8192/16384 -> 512
+  // panel width: 64.  128 (gprx_set_tuning) selects the 128-column kernels -- fused, or in split mode one diagonal
+  // workgroup + potrf_rows128_kernel per 128 columns; both bit-identical to the 64-column paths and both measured
+  // slower (64 cells of N = 4096: 203 us per 128 columns against 173 us: the 128 x 128 diagonal workgroup takes 100 us
+  // and the rows kernel, 16 dependent sub-panel steps at 2 workgroups per CU, is latency- rather than HBM-bound)
   const int pwidth = tune.panel_width ? tune.panel_width : NB;
   // bulk-update tile: batched cells fill the chip with 64 x 64 tiles already (4 workgroups per CU hide the C
   // read-modify-write; measured 1529 vs 1513 fits/s at 16 cells of N = 4096); a single matrix lets launch_gemm choose
@@ -799,9 +974,15 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       prof->panel_marks.push_back(prof->used);
       hipEventRecord(prof->next(), st);
     }
-    double* stage_out = diag_stage + (int64_t)c * PW;
+    double* stage_out = diag_stage + (int64_t)c * STAGE_LD;
     double* invd = inv_diag + (int64_t)(c / NB) * NB * NB;
-    if (pw == PW) {
+    if (pw == PW && split_panel) {
+      hipLaunchKernelGGL(potrf_panel128_kernel, dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, c, stage_out, prev_stage, prev_dst,
+                         prev_pw, cs, info_stride);
+      if (rows_below > 0)
+        hipLaunchKernelGGL(potrf_rows128_kernel, dim3((rows_below + R128_ROWS - 1) / R128_ROWS, batch), dim3(256), 0, st,
+                           Acc + (int64_t)PW * lda, lda, rows_below, (const double*)stage_out, cs);
+    } else if (pw == PW) {
       const int nchunks = (rows_below + PANEL128_ROWS - 1) / PANEL128_ROWS;
       hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, c,
                          stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);

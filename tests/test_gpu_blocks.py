@@ -178,16 +178,18 @@ def test_potrf_large_every_schedule(lib, panel, outer, tile, split, inblock):
 
 
 def test_split_panel_is_bit_identical_to_the_fused_panel(lib):
-    """The rows-only kernel of the split panel repeats the fused kernel's arithmetic with L11 read from the staging
-    area: the factors must agree bit for bit."""
+    """The rows-only kernels of the split panel (64 and 128 columns) repeat the fused kernel's arithmetic with L11 read
+    from the staging area, and the K = 64 update walks k in the same groups of four as the sub-panel updates: fused 64,
+    split 64, fused 128 and split 128 must all agree bit for bit."""
     n, extra = 1024, 64
     rng = np.random.default_rng(2)
     g = rng.standard_normal((n, 48))
     full = np.vstack([g @ g.T / 48 + np.eye(n), rng.standard_normal((extra, n))])
     outs = []
     try:
-        for split in (-1, 1):
+        for split, width in ((-1, 64), (1, 64), (-1, 128), (1, 128)):
             check(lib.gprx_set_tuning(b"split_panel", split))
+            check(lib.gprx_set_tuning(b"panel_width", width))
             dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
             info = C.c_int(0)
             check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
@@ -196,5 +198,7 @@ def test_split_panel_is_bit_identical_to_the_fused_panel(lib):
             dI.free()
     finally:
         lib.gprx_set_tuning(b"split_panel", 0)
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+        lib.gprx_set_tuning(b"panel_width", 0)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)

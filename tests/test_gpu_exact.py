@@ -130,7 +130,7 @@ def test_factorize_many_matches_single_calls_and_replays(lib):
             lib.gprx_destroy(C.c_void_p(handles[c]))
 
 
-@pytest.mark.parametrize("kernel,n,d,ard,cells", [("RBF", 700, 5, False, 5), ("Matern52", 1100, 8, True, 3), ("Matern12", 130, 2, False, 17)])
+@pytest.mark.parametrize("kernel,n,d,ard,cells", [("RBF", 700, 5, False, 5), ("Matern52", 1100, 8, True, 3), ("Matern12", 130, 2, False, 17), ("Matern32", 330, 3, False, 26), ("RBF", 1000, 4, True, 25)])
 def test_factorize_batch_bit_identical_and_selectable(lib, kernel, n, d, ard, cells):
     """gprx_factorize_batch: every kernel of the schedule launched once for all cells.  Losses must equal the
     single-cell call bit for bit (same kernels, same operation order per element), match the oracle to 1e-9, and
