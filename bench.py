@@ -222,255 +222,268 @@ def main():
         result["kernel_build_hbm"] = {"GBps": kmat_bytes / (ms[0] * 1e-3) / 1e9, "frac_of_8TBps": kmat_bytes / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0 and not args.no_extras and not args.batched_only:
-        extra = {}
-        # F2: objective + gradient
-        grad = np.zeros(3)
-        check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
-        t1 = time.perf_counter()
-        k2 = max(3, args.steps // 4)
-        for _ in range(k2):
-            check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
-        extra["F2_objective_grad_evals_per_s"] = k2 / (time.perf_counter() - t1)
-        # F2 batched: the same evaluation for all cells of the step by batched launches (gprx_objective_batch)
-        gl, gg = np.zeros(cells), np.zeros((cells, 3))
-        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, mask, ptr(gl), ptr(gg)), h)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, mask, ptr(gl), ptr(gg)), h)
-        extra["F2_batched_objective_grad_evals_per_s"] = 3 * cells / (time.perf_counter() - t1)
-        extra["F2_batched_tflops"] = extra["F2_batched_objective_grad_evals_per_s"] * N_TRAIN**3 / 1e12
-        # predict: mean + variance at 100k points, inputs and outputs resident in HBM
-        fit_one()
-        dxs = DeviceBuffer.from_array(xs, device)
-        dmean, dvar = DeviceBuffer(8 * N_TEST, device), DeviceBuffer(8 * N_TEST, device)
-        check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
-        check(lib.gprx_synchronize(h), h)
-        t1 = time.perf_counter()
-        check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
-        check(lib.gprx_synchronize(h), h)
-        tp = time.perf_counter() - t1
-        extra["predict_points_per_s"] = N_TEST / tp
-        extra["predict_tflops"] = (N_TRAIN**2 * N_TEST + 2.0 * N_TRAIN * N_TEST) / tp / 1e12
-        extra["predict_n_test"] = N_TEST
-        # BASELINE configs[3] per GPU: independent cells, each fitted (batched) and predicted at the shared 100k test points
-        # (gprx_predict_batch: host buffers in and out, i.e. PCIe-inclusive)
-        c4 = 4
-        pm, pv = np.zeros((c4, N_TEST)), np.zeros((c4, N_TEST))
-        t1 = time.perf_counter()
-        check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), N_TEST, ptr(pm), ptr(pv), 1), h)
-        tc4 = time.perf_counter() - t1
-        extra["C4_fit_plus_predict_100k_cells_per_s"] = c4 / tc4
-        extra["C4_seconds_for_10k_cells_on_8_gpus_extrapolated"] = 10000 / 8 / (c4 / tc4)
-        gpu_mean = dmean.to_array((N_TEST,))[:2000]
-        gpu_var = dvar.to_array((N_TEST,))[:2000]
-        # F3: BASELINE configs[2] -- Matern-5/2 ARD, 50 L-BFGS-B iterations on the exact LML
-        from gpras_amd.gpr import GPRAS
-
-        g3 = GPRAS("Matern52", device=device)
-        t1 = time.perf_counter()
-        g3.fit(x, y[:, :1], None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
-        t3 = time.perf_counter() - t1
-        extra["F3_lbfgs50_matern52_ard_seconds"] = t3
-        extra["F3_evaluations"] = g3.models[0].n_evals
-        extra["F3_fits_per_s"] = 1.0 / t3
-        # F3 over 16 modes of one training set in lock step (batched evaluations; bit-identical to the serial loop)
-        g16 = GPRAS("Matern52", device=device)
-        t1 = time.perf_counter()
-        g16.fit(x, y[:, :16], None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
-        t16 = time.perf_counter() - t1
-        extra["F3_lockstep_16_modes_seconds"] = t16
-        extra["F3_lockstep_fits_per_s"] = 16 / t16
-        extra["F3_lockstep_evaluations"] = int(sum(m.n_evals for m in g16.models))
-        del g16
-        # sparse model at a reference-realistic size (gpras example config: 10 modes, 50 inducing points; gpr.py:299):
-        # SGPR.training_loss + gradient evaluations, and the reference's default fit (two-stage Adam, 100 + 100 steps)
-        n_s, d_s, m_s = 4096, 10, 50
-        xsp, ysp, _ = make_regression(n_s, d_s, n_outputs=1, n_test=0, config=6, unit=0)
-        gs = GPRAS("RBF", device=device)
-        gs._init_models(xsp, ysp, m_s, "kmeans")
-        ms_model = gs.models[0]
-        ms_model.loss_and_grad()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            ms_model.loss_and_grad()
-        extra["sgpr_n4096_d10_m50_loss_grad_evals_per_s"] = 20 / (time.perf_counter() - t1)
-        t1 = time.perf_counter()
-        gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
-        extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
-        # the sparse path is launch-latency bound (~45 dependent launches per evaluation): all modes go through the SAME
-        # launches (gprx_objective_batch, cell index in every grid) -- 16 cells per call, then the default two-stage fit
-        # of 16 modes in lock step; for comparison the older scheme, one engine + host thread per mode (workers=8)
-        xs16, ys16, _ = make_regression(n_s, d_s, n_outputs=16, n_test=0, config=6, unit=1)
-        g16s = GPRAS("RBF", device=device)
-        g16s._init_models(xs16.astype(np.float64), ys16.astype(np.float64), m_s, "kmeans")
-        u16 = np.arange(16, dtype=np.int32)
-        th16 = np.stack([mm.theta() for mm in g16s.models])
-        z16 = np.stack([mm.Z for mm in g16s.models])
-        g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
-        t1 = time.perf_counter()
-        for _ in range(20):
-            g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
-        extra["sgpr_batched16_loss_grad_evals_per_s"] = 20 * 16 / (time.perf_counter() - t1)
-        t1 = time.perf_counter()
-        g16s.fit(xs16, ys16, m_s, "kmeans", "two-stage")
-        tl = time.perf_counter() - t1
-        extra["sgpr_16_modes_two_stage_fit_seconds_lockstep"] = tl
-        extra["sgpr_units_per_s_lockstep"] = 16 / tl
-        del g16s
-        g8 = GPRAS("RBF", device=device)
-        t1 = time.perf_counter()
-        g8.fit(xs16, ys16, m_s, "kmeans", "two-stage", workers=8)
-        t8 = time.perf_counter() - t1
-        extra["sgpr_16_modes_two_stage_fit_seconds_workers8"] = t8
-        extra["sgpr_units_per_s_workers8"] = 16 / t8
-        extra["sgpr_loss_grad_evals_per_s_workers8"] = sum(m.n_evals for m in g8.models) / t8
-        del g8
-        # the other sizes of the target: N = 1024 (batched cells) and BASELINE configs[4], N = 16384 d = 12 (one cell alone)
-        sizes = {}
-        c1 = 512  # smaller matrices need more cells per launch to fill the chip
-        x1, y1, _ = make_regression(1024, DIM, n_outputs=c1, n_test=0, config=2, unit=500)
-        h1 = C.c_void_p()
-        check(lib.gprx_create(device, 1024, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h1)))
-        check(lib.gprx_set_data(h1, ptr(x1), ptr(y1), c1), h1)
-        units1 = np.arange(c1, dtype=np.int32)
-        thetas1 = np.ascontiguousarray(np.tile(thetas, (c1 // cells + 1, 1))[:c1])
-        losses1, status1 = np.zeros(c1), np.zeros(c1, dtype=np.int32)
-        for _ in range(2):
-            check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
-        t1 = time.perf_counter()
-        for _ in range(10):
-            check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
-        sizes["N1024_d8_batched_fits_per_s"] = 10 * c1 / (time.perf_counter() - t1)
-        sizes["N1024_d8_cells_per_launch"] = c1
-        check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
-        t1 = time.perf_counter()
-        for _ in range(10):
-            check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
-        sizes["N1024_d8_single_cell_ms"] = 1e2 * (time.perf_counter() - t1)
-        lib.gprx_destroy(h1)
-        n5, d5 = 16384, 12
-        x5, y5, _ = make_regression(n5, d5, n_outputs=1, n_test=0, config=5, unit=0)
-        h5 = C.c_void_p()
-        check(lib.gprx_create(device, n5, d5, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h5)))
-        check(lib.gprx_set_data(h5, ptr(x5), ptr(y5), 1), h5)
-        th5 = np.ascontiguousarray([softplus_inv(1.0), softplus_inv(np.mean(np.abs(x5))), softplus_inv(1.0 - NOISE_LOWER)], dtype=np.float64)
-        check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5)
-        t5 = (time.perf_counter() - t1) / 3
-        ms5 = (C.c_double * 4)()
-        lib.gprx_last_timings(h5, ms5)
-        sizes["N16384_d12_fit_ms"] = 1e3 * t5
-        sizes["N16384_d12_fits_per_s"] = 1.0 / t5
-        sizes["N16384_d12_cholesky_tflops"] = n5**3 / 3 / (ms5[1] * 1e-3) / 1e12
-        sizes["N16384_d12_cholesky_frac_of_fp64_mfma_peak"] = sizes["N16384_d12_cholesky_tflops"] / FP64_MFMA_PEAK_TFLOPS
-        sizes["N16384_d12_kernel_build_GBps"] = (8.0 * n5 * (n5 + 64) / 2 + 8.0 * n5 * d5) / (ms5[0] * 1e-3) / 1e9
-        lib.gprx_destroy(h5)
-        extra["other_sizes"] = sizes
-        # N1: EOF projection either side of the GP path, device-resident: transform (T, cells) -> (T, k)
-        # and reverse (T, k) -> mean + variance fields (T, cells); HBM-bound, rates against the algorithmic bytes
-        from gpras_amd.preprocess import EOFProjector
-        from gpras_amd.synth import make_eof_state
-        from oracle import pca as opca
-
-        t_rows, n_cells, k_modes = 512, 200_000, 10
-        st = make_eof_state(n_cells, k_modes, 64, seed=7)
-        big = np.tile(st["x"], (t_rows // 64, 1))
-        proj = EOFProjector(st["dry"], st["elevations"], st["input_mean"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse", device=device)
-        cp = (n_cells + 15) // 16 * 16
-        padded = np.zeros((t_rows, cp))
-        padded[:, :n_cells] = big
-        dx = DeviceBuffer.from_array(padded, device)
-        dz = DeviceBuffer(8 * t_rows * k_modes, device)
-        dfull, dvfull = DeviceBuffer(8 * t_rows * n_cells, device), DeviceBuffer(8 * t_rows * n_cells, device)
-        times = {"transform": [], "reverse": []}
-        for rep in range(4):
-            t1 = time.perf_counter()
-            check(lib.gprx_pca_transform_dev(proj.handle, dx.ptr, t_rows, dz.ptr))
-            check(lib.gprx_pca_synchronize(proj.handle))
-            times["transform"].append(time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            check(lib.gprx_pca_reverse_dev(proj.handle, dz.ptr, dz.ptr, t_rows, dfull.ptr, dvfull.ptr))
-            check(lib.gprx_pca_synchronize(proj.handle))
-            times["reverse"].append(time.perf_counter() - t1)
-        tt, tr = min(times["transform"][1:]), min(times["reverse"][1:])
-        zs = dz.to_array((t_rows, k_modes))[:64]
-        args = (st["dry"], st["elevations"], st["input_mean"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse")
-        t1 = time.perf_counter()
-        zr = opca.transform(st["x"], *args)
-        tc = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        opca.reverse_transform(zr, np.abs(zr), *args)
-        tcr = time.perf_counter() - t1
-        extra["eof_projection"] = {
-            "shape": {"rows": t_rows, "cells": n_cells, "modes": k_modes},
-            "transform_ms": 1e3 * tt,
-            "transform_GBps_of_input_read_once": 8.0 * t_rows * n_cells / tt / 1e9,
-            "reverse_mean_var_ms": 1e3 * tr,
-            "reverse_GBps_of_output_written_once": 16.0 * t_rows * n_cells / tr / 1e9,
-            "parity_transform_rel_err_vs_oracle": float(np.max(np.abs(zs - zr)) / np.max(np.abs(zr))),
-            "cpu_oracle_rows_per_s": {"transform": 64 / tc, "reverse": 64 / tcr},
-            "gpu_rows_per_s": {"transform": t_rows / tt, "reverse": t_rows / tr},
-        }
-        # N3: fused metrics over the reconstructed fields (truth / prediction / confidence: three (T, cells) fields, read once)
-        drow, dcell, darg = DeviceBuffer(8 * t_rows * 4, device), DeviceBuffer(8 * 5 * n_cells, device), DeviceBuffer(4 * 2 * n_cells, device)
-        nmatch = C.c_uint64()
-        tmet = []
-        for rep in range(4):
-            t1 = time.perf_counter()
-            check(lib.gprx_metrics_dev(device, dfull.ptr, dx.ptr, dvfull.ptr, t_rows, n_cells, 2, 0.05, drow.ptr, dcell.ptr, darg.ptr, C.byref(nmatch)))
-            tmet.append(time.perf_counter() - t1)
-        tm = min(tmet[1:])
-        extra["field_metrics"] = {
-            "shape": {"rows": t_rows, "cells": n_cells, "t_tol": 2},
-            "ms": 1e3 * tm,
-            "GBps_of_three_fields_read_once": 24.0 * t_rows * n_cells / tm / 1e9,
-        }
-        proj.close()
-        for b in (dx, dz, dfull, dvfull, drow, dcell, darg):
-            b.free()
-        result["extra"] = extra
-
-        # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----
-        from oracle import exact as oex
-
-        cores = os.cpu_count() or 1
+        # (the secondary measurements must never cost the headline line: a failure is reported, not raised)
         try:
-            from threadpoolctl import threadpool_info
-
-            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-        except Exception:
-            blas_threads = cores
-        v0, l0, s0 = 1.0, float(np.mean(np.abs(x))), 1.0
-        best = np.inf
-        cpu_lml = None
-        for _ in range(3):
+            extra = {}
+            # F2: objective + gradient
+            grad = np.zeros(3)
+            check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
             t1 = time.perf_counter()
-            cpu_lml = oex.lml("RBF", x, y[:, 0], v0, l0, s0)
-            best = min(best, time.perf_counter() - t1)
-        t1 = time.perf_counter()
-        cm, cv = oex.predict("RBF", x, y[:, 0], v0, l0, s0, xs[:2000])
-        tcp = time.perf_counter() - t1
-        # parity of the benchmarked step itself, at full size
-        gpu_loss_check = -(cpu_lml + sum(-np.log(u) - 0.5 * np.log(2 * np.pi) - 0.5 * np.log(u) ** 2 for u in (v0, l0, s0)))
-        fit_one()
-        result["cpu_baseline"] = {
-            "value": 1.0 / best,
-            "unit": "fits/s",
-            "cores": int(min(cores, blas_threads)),
-            "kind": "port",
-            "sample": f"3 F1 fits (best of 3) at N={N_TRAIN} d={DIM} with oracle/exact.py (numpy + scipy LAPACK); predict on 2000 of the {N_TEST} points",
-            "predict_points_per_s": 2000 / tcp,
-            "host_cpu_count": cores,
-        }
-        fit_step()
-        result["parity_at_bench_size"] = {
-            "batched_cell0_equals_single_call_bitwise": bool(losses[0] == loss.value),
-            "loss_rel_err_vs_oracle": abs(loss.value - gpu_loss_check) / abs(gpu_loss_check),
-            "predict_mean_rel_err": float(np.max(np.abs(gpu_mean - cm)) / np.max(np.abs(cm))),
-            "predict_var_rel_err": float(np.max(np.abs(gpu_var - cv) / cv)),
-        }
+            k2 = max(3, args.steps // 4)
+            for _ in range(k2):
+                check(lib.gprx_objective(h, 0, ptr(theta), None, mask, C.byref(loss), ptr(grad)), h)
+            extra["F2_objective_grad_evals_per_s"] = k2 / (time.perf_counter() - t1)
+            # F2 batched: the same evaluation for all cells of the step by batched launches (gprx_objective_batch)
+            gl, gg = np.zeros(cells), np.zeros((cells, 3))
+            check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, mask, ptr(gl), ptr(gg)), h)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, mask, ptr(gl), ptr(gg)), h)
+            extra["F2_batched_objective_grad_evals_per_s"] = 3 * cells / (time.perf_counter() - t1)
+            extra["F2_batched_tflops"] = extra["F2_batched_objective_grad_evals_per_s"] * N_TRAIN**3 / 1e12
+            # predict: mean + variance at 100k points, inputs and outputs resident in HBM
+            fit_one()
+            dxs = DeviceBuffer.from_array(xs, device)
+            dmean, dvar = DeviceBuffer(8 * N_TEST, device), DeviceBuffer(8 * N_TEST, device)
+            check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
+            check(lib.gprx_synchronize(h), h)
+            t1 = time.perf_counter()
+            check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
+            check(lib.gprx_synchronize(h), h)
+            tp = time.perf_counter() - t1
+            extra["predict_points_per_s"] = N_TEST / tp
+            extra["predict_tflops"] = (N_TRAIN**2 * N_TEST + 2.0 * N_TRAIN * N_TEST) / tp / 1e12
+            extra["predict_n_test"] = N_TEST
+            # BASELINE configs[3] per GPU: independent cells, each fitted (batched) and predicted at the shared 100k test points
+            # (gprx_predict_batch: host buffers in and out, i.e. PCIe-inclusive)
+            c4 = 4
+            pm, pv = np.zeros((c4, N_TEST)), np.zeros((c4, N_TEST))
+            t1 = time.perf_counter()
+            check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), N_TEST, ptr(pm), ptr(pv), 1), h)
+            tc4 = time.perf_counter() - t1
+            extra["C4_fit_plus_predict_100k_cells_per_s"] = c4 / tc4
+            extra["C4_seconds_for_10k_cells_on_8_gpus_extrapolated"] = 10000 / 8 / (c4 / tc4)
+            gpu_mean = dmean.to_array((N_TEST,))[:2000]
+            gpu_var = dvar.to_array((N_TEST,))[:2000]
+            # F3: BASELINE configs[2] -- Matern-5/2 ARD, 50 L-BFGS-B iterations on the exact LML
+            from gpras_amd.gpr import GPRAS
+
+            g3 = GPRAS("Matern52", device=device)
+            t1 = time.perf_counter()
+            g3.fit(x, y[:, :1], None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
+            t3 = time.perf_counter() - t1
+            extra["F3_lbfgs50_matern52_ard_seconds"] = t3
+            extra["F3_evaluations"] = g3.models[0].n_evals
+            extra["F3_fits_per_s"] = 1.0 / t3
+            # F3 over 16 modes of one training set in lock step (batched evaluations; bit-identical to the serial loop)
+            g16 = GPRAS("Matern52", device=device)
+            t1 = time.perf_counter()
+            g16.fit(x, y[:, :16], None, optimization_method="L-BFGS-B", ard=True, max_iter=50)
+            t16 = time.perf_counter() - t1
+            extra["F3_lockstep_16_modes_seconds"] = t16
+            extra["F3_lockstep_fits_per_s"] = 16 / t16
+            extra["F3_lockstep_evaluations"] = int(sum(m.n_evals for m in g16.models))
+            del g16
+            # sparse model at a reference-realistic size (gpras example config: 10 modes, 50 inducing points; gpr.py:299):
+            # SGPR.training_loss + gradient evaluations, and the reference's default fit (two-stage Adam, 100 + 100 steps)
+            n_s, d_s, m_s = 4096, 10, 50
+            xsp, ysp, _ = make_regression(n_s, d_s, n_outputs=1, n_test=0, config=6, unit=0)
+            gs = GPRAS("RBF", device=device)
+            gs._init_models(xsp, ysp, m_s, "kmeans")
+            ms_model = gs.models[0]
+            ms_model.loss_and_grad()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                ms_model.loss_and_grad()
+            extra["sgpr_n4096_d10_m50_loss_grad_evals_per_s"] = 20 / (time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
+            extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
+            # the sparse path is launch-latency bound (~45 dependent launches per evaluation): all modes go through the SAME
+            # launches (gprx_objective_batch, cell index in every grid) -- 16 cells per call, then the default two-stage fit
+            # of 16 modes in lock step; for comparison the older scheme, one engine + host thread per mode (workers=8)
+            xs16, ys16, _ = make_regression(n_s, d_s, n_outputs=16, n_test=0, config=6, unit=1)
+            g16s = GPRAS("RBF", device=device)
+            g16s._init_models(xs16.astype(np.float64), ys16.astype(np.float64), m_s, "kmeans")
+            u16 = np.arange(16, dtype=np.int32)
+            th16 = np.stack([mm.theta() for mm in g16s.models])
+            z16 = np.stack([mm.Z for mm in g16s.models])
+            g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
+            extra["sgpr_batched16_loss_grad_evals_per_s"] = 20 * 16 / (time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            g16s.fit(xs16, ys16, m_s, "kmeans", "two-stage")
+            tl = time.perf_counter() - t1
+            extra["sgpr_16_modes_two_stage_fit_seconds_lockstep"] = tl
+            extra["sgpr_units_per_s_lockstep"] = 16 / tl
+            del g16s
+            g8 = GPRAS("RBF", device=device)
+            t1 = time.perf_counter()
+            g8.fit(xs16, ys16, m_s, "kmeans", "two-stage", workers=8)
+            t8 = time.perf_counter() - t1
+            extra["sgpr_16_modes_two_stage_fit_seconds_workers8"] = t8
+            extra["sgpr_units_per_s_workers8"] = 16 / t8
+            extra["sgpr_loss_grad_evals_per_s_workers8"] = sum(m.n_evals for m in g8.models) / t8
+            del g8
+            # the other sizes of the target: N = 1024 (batched cells) and BASELINE configs[4], N = 16384 d = 12 (one cell alone)
+            sizes = {}
+            c1 = 512  # smaller matrices need more cells per launch to fill the chip
+            x1, y1, _ = make_regression(1024, DIM, n_outputs=c1, n_test=0, config=2, unit=500)
+            h1 = C.c_void_p()
+            check(lib.gprx_create(device, 1024, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h1)))
+            check(lib.gprx_set_data(h1, ptr(x1), ptr(y1), c1), h1)
+            units1 = np.arange(c1, dtype=np.int32)
+            thetas1 = np.ascontiguousarray(np.tile(thetas, (c1 // cells + 1, 1))[:c1])
+            losses1, status1 = np.zeros(c1), np.zeros(c1, dtype=np.int32)
+            for _ in range(2):
+                check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
+            sizes["N1024_d8_batched_fits_per_s"] = 10 * c1 / (time.perf_counter() - t1)
+            sizes["N1024_d8_cells_per_launch"] = c1
+            check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
+            sizes["N1024_d8_single_cell_ms"] = 1e2 * (time.perf_counter() - t1)
+            lib.gprx_destroy(h1)
+            n5, d5 = 16384, 12
+            x5, y5, _ = make_regression(n5, d5, n_outputs=1, n_test=0, config=5, unit=0)
+            h5 = C.c_void_p()
+            check(lib.gprx_create(device, n5, d5, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h5)))
+            check(lib.gprx_set_data(h5, ptr(x5), ptr(y5), 1), h5)
+            th5 = np.ascontiguousarray([softplus_inv(1.0), softplus_inv(np.mean(np.abs(x5))), softplus_inv(1.0 - NOISE_LOWER)], dtype=np.float64)
+            check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5)
+            t5 = (time.perf_counter() - t1) / 3
+            ms5 = (C.c_double * 4)()
+            lib.gprx_last_timings(h5, ms5)
+            sizes["N16384_d12_fit_ms"] = 1e3 * t5
+            sizes["N16384_d12_fits_per_s"] = 1.0 / t5
+            sizes["N16384_d12_cholesky_tflops"] = n5**3 / 3 / (ms5[1] * 1e-3) / 1e12
+            sizes["N16384_d12_cholesky_frac_of_fp64_mfma_peak"] = sizes["N16384_d12_cholesky_tflops"] / FP64_MFMA_PEAK_TFLOPS
+            sizes["N16384_d12_kernel_build_GBps"] = (8.0 * n5 * (n5 + 64) / 2 + 8.0 * n5 * d5) / (ms5[0] * 1e-3) / 1e9
+            lib.gprx_destroy(h5)
+            extra["other_sizes"] = sizes
+            # N1: EOF projection either side of the GP path, device-resident: transform (T, cells) -> (T, k)
+            # and reverse (T, k) -> mean + variance fields (T, cells); HBM-bound, rates against the algorithmic bytes
+            from gpras_amd.preprocess import EOFProjector
+            from gpras_amd.synth import make_eof_state
+            from oracle import pca as opca
+
+            t_rows, n_cells, k_modes = 512, 200_000, 10
+            st = make_eof_state(n_cells, k_modes, 64, seed=7)
+            big = np.tile(st["x"], (t_rows // 64, 1))
+            proj = EOFProjector(st["dry"], st["elevations"], st["input_mean"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse", device=device)
+            cp = (n_cells + 15) // 16 * 16
+            padded = np.zeros((t_rows, cp))
+            padded[:, :n_cells] = big
+            dx = DeviceBuffer.from_array(padded, device)
+            dz = DeviceBuffer(8 * t_rows * k_modes, device)
+            dfull, dvfull = DeviceBuffer(8 * t_rows * n_cells, device), DeviceBuffer(8 * t_rows * n_cells, device)
+            times = {"transform": [], "reverse": []}
+            for rep in range(4):
+                t1 = time.perf_counter()
+                check(lib.gprx_pca_transform_dev(proj.handle, dx.ptr, t_rows, dz.ptr))
+                check(lib.gprx_pca_synchronize(proj.handle))
+                times["transform"].append(time.perf_counter() - t1)
+                t1 = time.perf_counter()
+                check(lib.gprx_pca_reverse_dev(proj.handle, dz.ptr, dz.ptr, t_rows, dfull.ptr, dvfull.ptr))
+                check(lib.gprx_pca_synchronize(proj.handle))
+                times["reverse"].append(time.perf_counter() - t1)
+            tt, tr = min(times["transform"][1:]), min(times["reverse"][1:])
+            zs = dz.to_array((t_rows, k_modes))[:64]
+            args = (st["dry"], st["elevations"], st["input_mean"], st["weights"], st["eofs"], st["x_mean"], st["x_std"], "wse")
+            t1 = time.perf_counter()
+            zr = opca.transform(st["x"], *args)
+            tc = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            opca.reverse_transform(zr, np.abs(zr), *args)
+            tcr = time.perf_counter() - t1
+            extra["eof_projection"] = {
+                "shape": {"rows": t_rows, "cells": n_cells, "modes": k_modes},
+                "transform_ms": 1e3 * tt,
+                "transform_GBps_of_input_read_once": 8.0 * t_rows * n_cells / tt / 1e9,
+                "reverse_mean_var_ms": 1e3 * tr,
+                "reverse_GBps_of_output_written_once": 16.0 * t_rows * n_cells / tr / 1e9,
+                "parity_transform_rel_err_vs_oracle": float(np.max(np.abs(zs - zr)) / np.max(np.abs(zr))),
+                "cpu_oracle_rows_per_s": {"transform": 64 / tc, "reverse": 64 / tcr},
+                "gpu_rows_per_s": {"transform": t_rows / tt, "reverse": t_rows / tr},
+            }
+            # N3: fused metrics over the reconstructed fields (truth / prediction / confidence: three (T, cells) fields, read once)
+            drow, dcell, darg = DeviceBuffer(8 * t_rows * 4, device), DeviceBuffer(8 * 5 * n_cells, device), DeviceBuffer(4 * 2 * n_cells, device)
+            nmatch = C.c_uint64()
+            tmet = []
+            for rep in range(4):
+                t1 = time.perf_counter()
+                check(lib.gprx_metrics_dev(device, dfull.ptr, dx.ptr, dvfull.ptr, t_rows, n_cells, 2, 0.05, drow.ptr, dcell.ptr, darg.ptr, C.byref(nmatch)))
+                tmet.append(time.perf_counter() - t1)
+            tm = min(tmet[1:])
+            extra["field_metrics"] = {
+                "shape": {"rows": t_rows, "cells": n_cells, "t_tol": 2},
+                "ms": 1e3 * tm,
+                "GBps_of_three_fields_read_once": 24.0 * t_rows * n_cells / tm / 1e9,
+            }
+            proj.close()
+            for b in (dx, dz, dfull, dvfull, drow, dcell, darg):
+                b.free()
+            result["extra"] = extra
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+
+            traceback.print_exc()
+            result["extra"] = extra
+            result["extra_error"] = f"{type(exc).__name__}: {exc}"
+        try:
+            # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same workload ----
+            from oracle import exact as oex
+
+            cores = os.cpu_count() or 1
+            try:
+                from threadpoolctl import threadpool_info
+
+                blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+            except Exception:
+                blas_threads = cores
+            v0, l0, s0 = 1.0, float(np.mean(np.abs(x))), 1.0
+            best = np.inf
+            cpu_lml = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                cpu_lml = oex.lml("RBF", x, y[:, 0], v0, l0, s0)
+                best = min(best, time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            cm, cv = oex.predict("RBF", x, y[:, 0], v0, l0, s0, xs[:2000])
+            tcp = time.perf_counter() - t1
+            # parity of the benchmarked step itself, at full size
+            gpu_loss_check = -(cpu_lml + sum(-np.log(u) - 0.5 * np.log(2 * np.pi) - 0.5 * np.log(u) ** 2 for u in (v0, l0, s0)))
+            fit_one()
+            result["cpu_baseline"] = {
+                "value": 1.0 / best,
+                "unit": "fits/s",
+                "cores": int(min(cores, blas_threads)),
+                "kind": "port",
+                "sample": f"3 F1 fits (best of 3) at N={N_TRAIN} d={DIM} with oracle/exact.py (numpy + scipy LAPACK); predict on 2000 of the {N_TEST} points",
+                "predict_points_per_s": 2000 / tcp,
+                "host_cpu_count": cores,
+            }
+            fit_step()
+            result["parity_at_bench_size"] = {
+                "batched_cell0_equals_single_call_bitwise": bool(losses[0] == loss.value),
+                "loss_rel_err_vs_oracle": abs(loss.value - gpu_loss_check) / abs(gpu_loss_check),
+                "predict_mean_rel_err": float(np.max(np.abs(gpu_mean - cm)) / np.max(np.abs(cm))),
+                "predict_var_rel_err": float(np.max(np.abs(gpu_var - cv) / cv)),
+            }
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+
+            traceback.print_exc()
+            result["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
 
     lib.gprx_destroy(h)
     if distributed:
