@@ -98,6 +98,31 @@ def test_bound_identities(data, kernel):
 
 
 @pytest.mark.parametrize("kernel", kn.KERNEL_NAMES)
+def test_sparse_bound_and_prediction_against_dense_textbook_formulas(data, kernel):
+    """Independent pin of the M < N path: Titsias' collapsed bound written densely,
+    ELBO = log N(y | 0, Qff + s I) - tr(Kff - Qff) / (2 s),  Qff = Kfu (Kuu + jitter I)^-1 Kuf,
+    and the VFE predictive equations with Sigma = (Kuu + Kuf Kfu / s)^-1 -- none of the Cholesky-based intermediates
+    (A, B, LB, c) of the restatement appear here."""
+    x, y, xs = data
+    v, l, s = 1.1, 0.8, 0.07
+    z = gpras_oracle.create_inducing(x, 24, "kmeans")
+    n = x.shape[0]
+    kuu = kn.kmat(kernel, z, z, v, l) + sgpr.JITTER * np.eye(z.shape[0])
+    kuf = kn.kmat(kernel, z, x, v, l)
+    qff = kuf.T @ np.linalg.solve(kuu, kuf)
+    cov = qff + s * np.eye(n)
+    sign, logdet = np.linalg.slogdet(cov)
+    dense = -0.5 * (n * np.log(2 * np.pi) + logdet + y @ np.linalg.solve(cov, y)) - (n * v - np.trace(qff)) / (2 * s)
+    assert sign > 0 and sgpr.elbo(kernel, x, y, z, v, l, s) == pytest.approx(dense, rel=1e-9)
+    sigma = np.linalg.inv(kuu + kuf @ kuf.T / s)
+    kus = kn.kmat(kernel, z, xs, v, l)
+    mean_dense = kus.T @ sigma @ kuf @ y / s
+    var_dense = v - np.sum(kus * (np.linalg.solve(kuu, kus) - sigma @ kus), axis=0) + s
+    mean, var = sgpr.predict(kernel, x, y, z, v, l, s, xs)
+    assert np.allclose(mean, mean_dense, rtol=1e-7, atol=1e-9) and np.allclose(var, var_dense, rtol=1e-7)
+
+
+@pytest.mark.parametrize("kernel", kn.KERNEL_NAMES)
 @pytest.mark.parametrize("ard", [False, True])
 def test_gradients_against_central_differences(kernel, ard):
     x, y, _ = make_regression(120, 3, 1, 0, config=9, unit=1)
