@@ -236,3 +236,23 @@ def test_multistart_quirks():
     assert model.mask[gpras_oracle.ZZ] is False  # Z was replaced by a plain array -> frozen (gpr.py:91)
     lo, hi = x.min(axis=0), x.max(axis=0)
     assert np.all(model.Z >= lo) and np.all(model.Z <= hi)
+
+
+def test_transforms_and_prior_against_scipy():
+    """tfp.distributions.LogNormal(0, 1).log_prob and the softplus bijector, pinned by scipy's implementations."""
+    from scipy.special import expit
+    from scipy.stats import lognorm
+
+    u = np.array([1e-3, 0.05, 0.7, 1.0, 3.0, 40.0])
+    assert np.allclose(tr.lognormal01_logpdf(u), lognorm(s=1.0).logpdf(u), rtol=1e-13, atol=0)
+    eps = 1e-6
+    num = (lognorm(s=1.0).logpdf(u * (1 + eps)) - lognorm(s=1.0).logpdf(u * (1 - eps))) / (2 * eps * u)
+    assert np.allclose(tr.lognormal01_dlogpdf(u), num, rtol=1e-6)
+    w = np.array([-30.0, -2.0, 0.0, 0.5413, 5.0, 40.0])
+    assert np.allclose(tr.softplus(w), np.logaddexp(0.0, w), rtol=1e-15)
+    assert np.allclose(tr.softplus_grad(w), expit(w), rtol=1e-13)
+    assert np.allclose(tr.softplus_inv(tr.softplus(w[1:])), w[1:], rtol=1e-12, atol=1e-12)
+    v, l, s = tr.constrain(0.3, np.array([0.2, -0.1]), -1.0)
+    assert s == pytest.approx(1e-6 + np.log1p(np.exp(-1.0)), rel=1e-15)  # gpflow's Gaussian likelihood floor
+    wv, wl, wn = tr.unconstrain(v, l, s)
+    assert wv == pytest.approx(0.3, rel=1e-12) and np.allclose(wl, [0.2, -0.1], rtol=1e-12) and wn == pytest.approx(-1.0, rel=1e-10)
