@@ -101,6 +101,20 @@ def test_random_sparse(lib, seed):
         cond = np.linalg.cond(okn.kmat(kernel, z, z, variance, lsc0) + 1e-6 * np.eye(m))
         tol = 1e-7 * max(1.0, cond / 1e6)
         assert np.max(np.abs(grad - ref)) <= tol * max(1.0, np.max(np.abs(ref))), (kernel, n, d, m, ard, cond)
+        # the same cell plus perturbed ones through the batched entry point: bit-identical to single calls
+        cells = int(rng.integers(2, 5))
+        thetas = np.ascontiguousarray(theta[None, :] + np.concatenate([np.zeros((1, theta.size)), 0.05 * rng.standard_normal((cells - 1, theta.size))]))
+        zs = np.ascontiguousarray(z[None] + np.concatenate([np.zeros((1, m, d)), 1e-3 * rng.standard_normal((cells - 1, m, d))]))
+        cunits = np.ascontiguousarray(rng.integers(0, units, size=cells), dtype=np.int32)
+        cunits[0] = unit
+        bl, bg = np.zeros(cells), np.zeros((cells, 2 + nl + m * d))
+        check(lib.gprx_objective_batch(h, cells, ptr(cunits), ptr(thetas), ptr(zs), 15, ptr(bl), ptr(bg)), h)
+        assert bl[0] == loss.value and np.array_equal(bg[0], grad)
+        for c in range(1, cells):
+            sl, sg = C.c_double(), np.zeros(2 + nl + m * d)
+            check(lib.gprx_objective(h, int(cunits[c]), ptr(np.ascontiguousarray(thetas[c])), ptr(np.ascontiguousarray(zs[c])), 15, C.byref(sl), ptr(sg)), h)
+            assert sl.value == bl[c] and np.array_equal(sg, bg[c])
+        check(lib.gprx_objective(h, unit, ptr(theta), ptr(z), 15, C.byref(loss), ptr(grad)), h)  # state for predict below
         mean, var = np.zeros(9), np.zeros(9)
         check(lib.gprx_predict(h, ptr(xs), 9, ptr(mean), ptr(var), 1), h)
         lsc = ls if ard else float(ls[0])
