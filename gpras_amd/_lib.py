@@ -17,6 +17,7 @@ GPRX_OK, GPRX_EINVAL, GPRX_ENOTPD, GPRX_EHIP, GPRX_ENOMEM, GPRX_ESTATE = range(6
 TRAIN_VARIANCE, TRAIN_LENGTHSCALE, TRAIN_NOISE, TRAIN_Z = 1, 2, 4, 8
 GEMM_C_LOWER, GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER = 1, 2, 4, 8, 16
 
+DISTANCE_FORMS = {"difference": 0, "expanded": 1}
 KERNEL_IDS = {"RBF": 0, "Matern12": 1, "Matern32": 2, "Matern52": 3, "Exponential": 4}
 
 
@@ -38,6 +39,7 @@ PROTOTYPES = {
     "gprx_destroy": (C.c_int, [_vp]),
     "gprx_set_stream": (C.c_int, [_vp, _vp]),
     "gprx_synchronize": (C.c_int, [_vp]),
+    "gprx_set_distance_form": (C.c_int, [_vp, C.c_int]),
     "gprx_set_data": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "gprx_objective": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dp, _vp]),
     "gprx_factorize": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp]),
@@ -66,6 +68,7 @@ PROTOTYPES = {
     "gprx_pca_synchronize": (C.c_int, [_vp]),
     "gprx_metrics": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "gprx_metrics_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "gprx_gather_rows": (C.c_int, [C.c_int, _vp, _i64, _i64, _vp, _vp]),
     "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),
     "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),
     "gprx_potrf": (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _ip]),

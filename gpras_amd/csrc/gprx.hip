@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,7 @@ struct gprx_ctx {
   bool own_stream = false;
   int64_t n = 0, m = 0, np = 0, mp = 0;
   int d = 0, kid = 0, ard = 0, nlen = 1, ntheta = 3, n_units = 0;
+  int dist_form = 0;  // GPRX_DIST_DIFFERENCE / GPRX_DIST_EXPANDED
   std::string err;
   // data
   Buf X, Y, Z, invls, alpha, red, Kmat, invD, Xinv, Tmp, partial, xs, Ks, pred;
@@ -103,6 +105,13 @@ struct gprx_pca_ctx {
 };
 
 namespace {
+
+// kernel-matrix and trace launches evaluate r2 in the handle's distance form (gprx_set_distance_form)
+template <class Args>
+Args with_form(Args a, gprx_handle h) {
+  a.form = h->dist_form;
+  return a;
+}
 
 int fail(gprx_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -242,7 +251,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   }
   KmatArgs ka{h->X.p, h->X.p, h->invls.p, h->Kmat.p, ld, (int)h->n, (int)h->n, h->d, np, np, t.variance, t.noise, 1, 1.0,
               capture ? h->gparams : nullptr, 0};
-  HIPCHK(h, launch_kmat(st, h->kid, ka));
+  HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
   hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(64), dim3(256), 0, st, h->Kmat.p + (int64_t)np * ld, ld, h->Y.p + (int64_t)unit * h->np,
                      (int)h->n, np, NB);
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[1], st));
@@ -472,7 +481,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
     ka.cell_par = cpar;
     ka.out_stride = cs;
-    HIPCHK(h, launch_kmat(gs, h->kid, ka, cnt));
+    HIPCHK(h, launch_kmat(gs, h->kid, with_form(ka, h), cnt));
     hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
@@ -591,7 +600,7 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   ta.w_stride = gs;
   ta.uv_stride = cs;
   ta.partial_stride = ps;
-  HIPCHK(h, launch_trace(st, h->kid, ta, tiles * tiles, count));
+  HIPCHK(h, launch_trace(st, h->kid, with_form(ta, h), tiles * tiles, count));
   double* sums0 = h->gpartial.p + ps * count;
   hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)h->gpartial.p, tiles * tiles, width, sums0, ps);
   std::vector<double> host((size_t)width * count);
@@ -632,7 +641,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   const int width = 2 + h->d;
   if ((rc = ensure(h, h->partial, sizeof(double) * ((size_t)tiles * tiles * width + width)))) return rc;
   TraceArgs ta{h->X.p, h->X.p, h->invls.p, h->Tmp.p, ld, h->alpha.p, h->alpha.p, -1.0, 1.0, (int)h->n, (int)h->n, h->d, t.variance, 1, h->partial.p, nullptr, 0, tiles};
-  HIPCHK(h, launch_trace(st, h->kid, ta, tiles * tiles));
+  HIPCHK(h, launch_trace(st, h->kid, with_form(ta, h), tiles * tiles));
   double* sums = h->partial.p + (size_t)tiles * tiles * width;
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, h->partial.p, tiles * tiles, width, sums);
   std::vector<double> host(width);
@@ -691,9 +700,9 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   const double s = t.noise;
   HIPCHK(h, hipEventRecord(h->ev[0], st));
   KmatArgs kp{h->Z.p, h->X.p, h->invls.p, h->P.p, np, m, n, h->d, mp, np, t.variance, 0.0, 0, 0.0, nullptr, 0};
-  HIPCHK(h, launch_kmat(st, h->kid, kp));
+  HIPCHK(h, launch_kmat(st, h->kid, with_form(kp, h)));
   KmatArgs kq{h->Z.p, h->Z.p, h->invls.p, h->Qm.p, mp, m, m, h->d, mp, mp, t.variance, JITTER, 2, 1.0, nullptr, 0};
-  HIPCHK(h, launch_kmat(st, h->kid, kq));
+  HIPCHK(h, launch_kmat(st, h->kid, with_form(kq, h)));
   HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
   HIPCHK(h, potrf_lower(st, h->Qm.p, mp, mp, 0, h->invDL.p, h->info, h->dstage.p, nullptr, nullptr));
@@ -789,9 +798,9 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   double* partQ = partP + part_p;
   double* sums = partQ + part_q;
   TraceArgs tp{h->Z.p, h->X.p, h->invls.p, h->WP.p, np, mvec, yu, 1.0 / s, 1.0 / s, m, n, d, t.variance, 0, partP, h->WHP.p, np, tiles_n};
-  HIPCHK(h, launch_trace(st, h->kid, tp, tiles_m * tiles_n));
+  HIPCHK(h, launch_trace(st, h->kid, with_form(tp, h), tiles_m * tiles_n));
   TraceArgs tq{h->Z.p, h->Z.p, h->invls.p, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, t.variance, 0, partQ, h->WHQ.p, mp, tiles_m};
-  HIPCHK(h, launch_trace(st, h->kid, tq, tiles_m * tiles_m));
+  HIPCHK(h, launch_trace(st, h->kid, with_form(tq, h), tiles_m * tiles_m));
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums);
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width);
   hipLaunchKernelGGL(dz_kernel, dim3(m * d), dim3(256), 0, st, (const double*)h->Z.p, (const double*)h->X.p, (const double*)h->WHP.p,
@@ -933,14 +942,14 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   kp.out_stride = ss;
   kp.a_stride = ss;
   kp.diag_const = 1;
-  HIPCHK(h, launch_kmat(st, h->kid, kp, count));
+  HIPCHK(h, launch_kmat(st, h->kid, with_form(kp, h), count));
   KmatArgs kq{A0 + L.oZ, A0 + L.oZ, nullptr, A0 + L.oQm, mp, m, m, d, mp, mp, 0.0, JITTER, 2, 1.0, nullptr, 0};
   kq.cell_par = cpar;
   kq.out_stride = ss;
   kq.a_stride = ss;
   kq.b_stride = ss;
   kq.diag_const = 1;
-  HIPCHK(h, launch_kmat(st, h->kid, kq, count));
+  HIPCHK(h, launch_kmat(st, h->kid, with_form(kq, h), count));
   int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
   HIPCHK(h, potrf_lower(st, A0 + L.oQm, mp, mp, 0, A0 + L.oInvDL, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES));
   HIPCHK(h, hipMemcpy2DAsync(A0 + L.oAm, pitch, A0 + L.oP, pitch, sizeof(double) * (size_t)mp * np, count, hipMemcpyDeviceToDevice, st));
@@ -1004,7 +1013,7 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     tp.a_stride = ss;
     tp.wh_stride = ss;
     tp.scale_inv_noise = 1;
-    HIPCHK(h, launch_trace(st, h->kid, tp, tiles_m * tiles_n, count));
+    HIPCHK(h, launch_trace(st, h->kid, with_form(tp, h), tiles_m * tiles_n, count));
     TraceArgs tq{A0 + L.oZ, A0 + L.oZ, nullptr, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, 0.0, 0, partQ, A0 + L.oWHQ, mp, tiles_m};
     tq.cell_par = cpar;
     tq.w_stride = ss;
@@ -1012,7 +1021,7 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     tq.a_stride = ss;
     tq.b_stride = ss;
     tq.wh_stride = ss;
-    HIPCHK(h, launch_trace(st, h->kid, tq, tiles_m * tiles_m, count));
+    HIPCHK(h, launch_trace(st, h->kid, with_form(tq, h), tiles_m * tiles_m, count));
     hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums, ss, ss);
     hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width, ss, ss);
     hipLaunchKernelGGL(dz_kernel, dim3(m * d, count), dim3(256), 0, st, (const double*)(A0 + L.oZ), (const double*)h->X.p,
@@ -1178,6 +1187,21 @@ int gprx_set_stream(gprx_handle h, void* hip_stream) {
   }
   h->stream = (hipStream_t)hip_stream;
   h->own_stream = false;
+  return GPRX_OK;
+}
+
+int gprx_set_distance_form(gprx_handle h, int form) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (form != GPRX_DIST_DIFFERENCE && form != GPRX_DIST_EXPANDED) return fail(h, GPRX_EINVAL, "unknown distance form");
+  if (form != h->dist_form) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dist_form = form;
+    h->factorized = false;  // resident factorisations (and captured graphs) were built with the other form
+    h->have_linv = false;
+    drop_graphs(h);
+    std::fill(h->slot_ok.begin(), h->slot_ok.end(), 0);
+  }
   return GPRX_OK;
 }
 
@@ -1451,7 +1475,7 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
       const int ts = (int)std::min<int64_t>(tile, ns - t0);
       const int tsp = (int)round_up(ts, NB);
       KmatArgs ka{h->Z.p, xs_dev + t0 * h->d, h->invls.p, h->Ks.p, tile, m, ts, h->d, mp, tsp, h->variance, 0.0, 0, 0.0, nullptr, 0};
-      HIPCHK(h, launch_kmat(st, h->kid, ka));
+      HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
       dim3 grid((ts + 255) / 256, nchunks);
       HIPCHK(h, trsm_lower_left(st, h->Qm.p, mp, h->invDL.p, h->Ks.p, tile, mp, tsp));
       hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, (const double*)nullptr, mp, ts, rows_per_chunk,
@@ -1497,7 +1521,7 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
       const int ts = (int)std::min<int64_t>(tile, ns - t0);
       const int tsp = (int)round_up(ts, NB);
       KmatArgs ka{xs_dev + t0 * h->d, h->X.p, h->invls.p, h->Ks.p, ld, ts, (int)h->n, h->d, tsp, np, h->variance, 0.0, 0, 0.0, nullptr, 0};
-      HIPCHK(h, launch_kmat(st, h->kid, ka));
+      HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
       hipLaunchKernelGGL(rowreduce_kernel, dim3((ts + 3) / 4), dim3(256), 0, st, (const double*)h->Ks.p, ld, (const double*)h->alpha.p, ts, np, 0.0,
                          1.0, mean_dev + t0);
       HIPCHK(h, launch_gemm(st, 0, 1, tsp, np, np, 1.0, h->Ks.p, ld, h->Xinv.p, ld, 0.0, Vbuf, ld, GEMM_B_UPPER, 128));
@@ -1513,7 +1537,7 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
     const int ts = (int)std::min<int64_t>(tile, ns - t0);
     const int tsp = (int)round_up(ts, NB);
     KmatArgs ka{h->X.p, xs_dev + t0 * h->d, h->invls.p, h->Ks.p, tile, (int)h->n, ts, h->d, np, tsp, h->variance, 0.0, 0, 0.0, nullptr, 0};
-    HIPCHK(h, launch_kmat(st, h->kid, ka));
+    HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
     dim3 grid((ts + 255) / 256, nchunks);
     hipLaunchKernelGGL(colreduce_partial, grid, dim3(256), 0, st, h->Ks.p, (int64_t)tile, h->alpha.p, np, ts, rows_per_chunk, h->pred.p);
     hipLaunchKernelGGL(colreduce_final, dim3((ts + 255) / 256), dim3(256), 0, st, h->pred.p, nchunks, ts, 0.0, 1.0, 0, mean_dev + t0);
@@ -1819,6 +1843,34 @@ int gprx_metrics(int device, const double* x, const double* y, const double* con
   return rc;
 }
 
+int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t cells, const int64_t* idx, double* out) {
+  if (!field_dev || !idx || !out) return fail(nullptr, GPRX_EINVAL, "null argument");
+  if (rows <= 0 || cells <= 0) return fail(nullptr, GPRX_EINVAL, "rows and cells must be positive");
+  std::vector<int64_t> wrapped(idx, idx + cells);
+  for (int64_t c = 0; c < cells; ++c) {
+    if (wrapped[c] < -rows || wrapped[c] >= rows) {
+      char msg[160];
+      snprintf(msg, sizeof msg, "index %lld is out of bounds for axis 0 with size %lld", (long long)idx[c], (long long)rows);
+      return fail(nullptr, GPRX_EINVAL, msg);
+    }
+    if (wrapped[c] < 0) wrapped[c] += rows;
+  }
+  HIPCHK(nullptr, hipSetDevice(device));
+  int64_t* didx = nullptr;
+  double* dout = nullptr;
+  hipError_t e = hipMalloc((void**)&didx, sizeof(int64_t) * cells);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(double) * cells);
+  if (e == hipSuccess) e = hipMemcpy(didx, wrapped.data(), sizeof(int64_t) * cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, nullptr, field_dev, cells, (const int64_t*)didx, dout);
+    e = hipMemcpy(out, dout, sizeof(double) * cells, hipMemcpyDeviceToHost);  // synchronises
+  }
+  if (didx) hipFree(didx);
+  if (dout) hipFree(dout);
+  HIPCHK(nullptr, e);
+  return GPRX_OK;
+}
+
 int gprx_dev_malloc(int device, int64_t bytes, void** out) {
   if (!out || bytes < 0) return fail(nullptr, GPRX_EINVAL, "bad argument");
   HIPCHK(nullptr, hipSetDevice(device));
@@ -1847,12 +1899,16 @@ int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const 
               int mode) {
   if (!a_dev || !b_dev || !ls_host || !out_dev) return fail(nullptr, GPRX_EINVAL, "null argument");
   if (n1p % NB || n2p % NB || ld % 2 || n1p < n1 || n2p < n2 || ld < n2p) return fail(nullptr, GPRX_EINVAL, "padded sizes must be multiples of 64");
+  if (mode < 0 || mode > 6) return fail(nullptr, GPRX_EINVAL, "bad kernel id or mode");
+  const int form = (mode & 4) ? GPRX_DIST_EXPANDED : GPRX_DIST_DIFFERENCE;  // mode + 4: gpflow's expanded distance form
+  mode &= 3;
   if (kernel_id < 0 || kernel_id > 4 || mode < 0 || mode > 2) return fail(nullptr, GPRX_EINVAL, "bad kernel id or mode");
   HIPCHK(nullptr, hipSetDevice(device));
   double* dinv = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dinv, sizeof(double) * d));
   HIPCHK(nullptr, hipMemcpy(dinv, ls_host, sizeof(double) * d, hipMemcpyHostToDevice));
   KmatArgs ka{a_dev, b_dev, dinv, out_dev, ld, (int)n1, (int)n2, d, (int)n1p, (int)n2p, variance, diag_add, mode, mode ? 1.0 : 0.0, nullptr, 0};
+  ka.form = form;
   hipError_t e = launch_kmat(nullptr, kernel_id, ka);
   hipError_t e2 = hipDeviceSynchronize();
   hipFree(dinv);

@@ -36,6 +36,7 @@ struct TraceArgs {
   int64_t w_stride = 0, uv_stride = 0, partial_stride = 0;
   int64_t a_stride = 0, b_stride = 0, v_stride = -1, wh_stride = 0;  // v_stride < 0: v advances like u
   int scale_inv_noise = 0;  // 1: w_scale = uv_scale = 1 / table[1] (the sparse model's 1 / s)
+  int form = 0;             // distance form of r2 inside g and h (kmat.h); the factors ds_k of the derivatives stay differences
 };
 
 // One workgroup per 64 x 64 tile.  Thread mapping as kmat_kernel: 8 rows x 2 columns per thread.
@@ -92,21 +93,55 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
   double r2[8][2];
 #pragma unroll
   for (int it = 0; it < 8; ++it) r2[it][0] = r2[it][1] = 0.0;
+  double na[8], nb[2] = {0.0, 0.0};  // expanded form only (kmat.h)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) na[it] = 0.0;
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
     stage(k0);
     __syncthreads();
+    if (p.form == 0) {
 #pragma unroll
-    for (int kk = 0; kk < KM_DC; ++kk) {
-      const d2 bv = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
+      for (int kk = 0; kk < KM_DC; ++kk) {
+        const d2 bv = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const double av = sA[wave * 16 + 2 * it + rsub][kk];
+          const double d0 = av - bv.x, d1 = av - bv.y;
+          r2[it][0] = __builtin_fma(d0, d0, r2[it][0]);
+          r2[it][1] = __builtin_fma(d1, d1, r2[it][1]);
+        }
+      }
+    } else {
+      double b0[KM_DC], b1[KM_DC];
+#pragma unroll
+      for (int kk = 0; kk < KM_DC; ++kk) {
+        const d2 bv = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
+        b0[kk] = bv.x;
+        b1[kk] = bv.y;
+      }
+      sqnorm_accumulate(nb[0], b0);
+      sqnorm_accumulate(nb[1], b1);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const double av = sA[wave * 16 + 2 * it + rsub][kk];
-        const double d0 = av - bv.x, d1 = av - bv.y;
-        r2[it][0] = __builtin_fma(d0, d0, r2[it][0]);
-        r2[it][1] = __builtin_fma(d1, d1, r2[it][1]);
+        double av[KM_DC];
+#pragma unroll
+        for (int kk = 0; kk < KM_DC; ++kk) av[kk] = sA[wave * 16 + 2 * it + rsub][kk];
+        sqnorm_accumulate(na[it], av);
+#pragma unroll
+        for (int kk = 0; kk < KM_DC; ++kk) {
+          r2[it][0] = __builtin_fma(av[kk], b0[kk], r2[it][0]);
+          r2[it][1] = __builtin_fma(av[kk], b1[kk], r2[it][1]);
+        }
       }
     }
     __syncthreads();
+  }
+  if (p.form != 0) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      r2[it][0] = expanded_r2(na[it], nb[0], r2[it][0]);
+      r2[it][1] = expanded_r2(na[it], nb[1], r2[it][1]);
+    }
   }
 
   // weights and correlation terms

@@ -1,7 +1,9 @@
 // Stationary kernel-matrix build (RBF, Matern-1/2, -3/2, -5/2, gpflow "Exponential").
 //
 //   out[i, j] = variance * g(r2(a_i, b_j)) + (i == j ? diag_add : 0),
-//   r2 = sum_k ((a_ik - b_jk) / l_k)^2      (difference form: no cancellation, r2(a, a) == 0)
+//   r2 = sum_k ((a_ik - b_jk) / l_k)^2      (difference form, the default: no cancellation, r2(a, a) == 0)
+//   r2 = |a_i/l|^2 + |b_j/l|^2 - 2 (a_i/l).(b_j/l)   (form == 1: gpflow's literal arithmetic, utilities/ops.py
+//        square_distance: squares rounded then summed in k order, the dot product as an fma chain in k order)
 //
 // Replaces gpflow's kernel evaluation inside SGPR (Kuf, Kuu, Kus; k(X, X) + s I for the exact
 // specialisation).  HBM-write bound: each 64 x 64 output tile costs 32 KiB of stores against
@@ -65,6 +67,21 @@ __device__ __forceinline__ void corr_gh(double r2, double& g, double& h) {
   }
 }
 
+// gpflow's square_distance (utilities/ops.py): Xs = reduce_sum(square(X), -1) -- every square rounded, then added in k
+// order --, dist = -2 X X2^T + Xs + X2s.  No fused multiply-add in the norms (a TensorFlow reduce_sum over rounded squares).
+__device__ __forceinline__ void sqnorm_accumulate(double& acc, const double (&v)[8]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const double sq = v[kk] * v[kk];
+    acc = acc + sq;
+  }
+}
+__device__ __forceinline__ double expanded_r2(double na, double nb, double dot) {
+#pragma clang fp contract(off)
+  return (na + nb) - 2.0 * dot;
+}
+
 struct KmatArgs {
   const double* a;       // (n1, d)
   const double* b;       // (n2, d)
@@ -84,6 +101,7 @@ struct KmatArgs {
   int64_t out_stride = 0;
   int64_t a_stride = 0, b_stride = 0;  // per-cell point sets (inducing inputs); 0: shared
   int diag_const = 0;                  // 1: keep diag_add as given (jitter) instead of the table's [1]
+  int form = 0;                        // 0: difference form, 1: gpflow's expanded form (see the header comment)
 };
 constexpr int CELL_PAR = 72;
 constexpr int CELL_PAR_LS = 8;
@@ -112,6 +130,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   double acc[8][2];
 #pragma unroll
   for (int it = 0; it < 8; ++it) acc[it][0] = acc[it][1] = 0.0;
+  double na[8], nb[2] = {0.0, 0.0};  // expanded form only: squared norms of this thread's 8 row points / 2 column points
+#pragma unroll
+  for (int it = 0; it < 8; ++it) na[it] = 0.0;
 
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
     // 64 points x 8 coords for each side = 512 + 512 values, 256 threads -> 2 + 2 each
@@ -137,18 +158,43 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
       b0[kk] = v.x;
       b1[kk] = v.y;
     }
+    if (p.form == 0) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = wave * 16 + 2 * it + rsub;
+      for (int it = 0; it < 8; ++it) {
+        const int row = wave * 16 + 2 * it + rsub;
 #pragma unroll
-      for (int kk = 0; kk < KM_DC; ++kk) {
-        const double a = sA[row][kk];
-        const double d0 = a - b0[kk], d1 = a - b1[kk];
-        acc[it][0] = __builtin_fma(d0, d0, acc[it][0]);
-        acc[it][1] = __builtin_fma(d1, d1, acc[it][1]);
+        for (int kk = 0; kk < KM_DC; ++kk) {
+          const double a = sA[row][kk];
+          const double d0 = a - b0[kk], d1 = a - b1[kk];
+          acc[it][0] = __builtin_fma(d0, d0, acc[it][0]);
+          acc[it][1] = __builtin_fma(d1, d1, acc[it][1]);
+        }
+      }
+    } else {
+      sqnorm_accumulate(nb[0], b0);
+      sqnorm_accumulate(nb[1], b1);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = wave * 16 + 2 * it + rsub;
+        double av[KM_DC];
+#pragma unroll
+        for (int kk = 0; kk < KM_DC; ++kk) av[kk] = sA[row][kk];
+        sqnorm_accumulate(na[it], av);
+#pragma unroll
+        for (int kk = 0; kk < KM_DC; ++kk) {  // (padding coordinates are zero: they add exact zeros)
+          acc[it][0] = __builtin_fma(av[kk], b0[kk], acc[it][0]);
+          acc[it][1] = __builtin_fma(av[kk], b1[kk], acc[it][1]);
+        }
       }
     }
     __syncthreads();
+  }
+  if (p.form != 0) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      acc[it][0] = expanded_r2(na[it], nb[0], acc[it][0]);
+      acc[it][1] = expanded_r2(na[it], nb[1], acc[it][1]);
+    }
   }
 
   if (p.dparams) {

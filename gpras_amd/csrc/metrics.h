@@ -140,4 +140,12 @@ __global__ __launch_bounds__(256) void metrics_rows_kernel(const double* __restr
   if (threadIdx.x < 4) row_out[t * 4 + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
 }
 
+// out[c] = field[idx[c], c]: the cached-argmax gathers x[x_mts, np.arange(cells)] of gpras/metrics.py:119-121 (and
+// every *_mts function after it) for CALLER-SUPPLIED timesteps; idx already wrapped to [0, rows) on the host.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ field, int64_t cells, const int64_t* __restrict__ idx,
+                                                          double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < cells) out[c] = field[idx[c] * cells + c];
+}
+
 }  // namespace gprx

@@ -21,7 +21,7 @@ class Engine:
     (``SGPR`` at ``/root/reference/gpras/gpr.py:299``).
     """
 
-    def __init__(self, kernel: str, x, y, n_inducing: int = 0, ard: bool = False, device: int = 0):
+    def __init__(self, kernel: str, x, y, n_inducing: int = 0, ard: bool = False, device: int = 0, distance_form: str = "difference"):
         self._lib = _lib.load()
         self.kernel = kernel
         kernel_id = KERNEL_IDS[kernel]  # KeyError for unknown names, as gpr.py:230
@@ -40,6 +40,15 @@ class Engine:
         self._h = C.c_void_p()
         check(self._lib.gprx_create(device, self.n, self.d, self.m, kernel_id, int(self.ard), C.byref(self._h)))
         check(self._lib.gprx_set_data(self._h, ptr(x), ptr(y), self.n_units), self._h)
+        self.distance_form = "difference"
+        if distance_form != "difference":
+            self.set_distance_form(distance_form)
+
+    def set_distance_form(self, form: str) -> None:
+        """``"difference"`` (default: r2 = sum ((a - b) / l)^2) or ``"expanded"`` (gpflow's literal
+        ``|a|^2 + |b|^2 - 2 a.b``) for every kernel evaluation of this engine (``gprx_set_distance_form``)."""
+        check(self._lib.gprx_set_distance_form(self._h, _lib.DISTANCE_FORMS[form]), self._h)
+        self.distance_form = form
 
     # -- lifetime -------------------------------------------------------------------------------
     def close(self):

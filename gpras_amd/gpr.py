@@ -40,8 +40,11 @@ FILE_FORMAT = "gpras_amd-1"
 class GPRAS:
     """Gaussian Process Regression for HEC-RAS model upskilling and emulation."""
 
-    def __init__(self, kernel: KernelType, device: int = 0) -> None:
+    def __init__(self, kernel: KernelType, device: int = 0, distance_form: str = "difference") -> None:
+        """``distance_form`` (extension): ``"difference"`` (default) or ``"expanded"`` -- the arithmetic form of the scaled
+        squared distance inside the kernels; ``"expanded"`` is gpflow's literal ``|a|^2 + |b|^2 - 2 a.b``."""
         self.kernel_str = kernel
+        self.distance_form = distance_form
         if kernel in _REFERENCE_ONLY:
             raise NotImplementedError(
                 f"kernel {kernel!r} is listed by the reference but cannot be built by its own fit() "
@@ -135,7 +138,7 @@ class GPRAS:
             eng.close()
         n_eng = max(1, min(int(workers), y.shape[1]))
         m = 0 if inducing is None else inducing.shape[0]
-        self.engines = [Engine(self.kernel_str, x, y, m, ard=self.ard, device=self.device) for _ in range(n_eng)]
+        self.engines = [Engine(self.kernel_str, x, y, m, ard=self.ard, device=self.device, distance_form=self.distance_form) for _ in range(n_eng)]
         self.engine = self.engines[0]
         # variance 1, lengthscale mean|x| (gpr.py:289, :298); Gaussian likelihood variance 1.0 (gpflow default)
         self.models = [GPModel(self.engines[i % n_eng], i, inducing, 1.0, ini_length, 1.0) for i in range(y.shape[1])]

@@ -76,6 +76,17 @@ int gprx_destroy(gprx_handle h);
 int gprx_set_stream(gprx_handle h, void* hip_stream);
 int gprx_synchronize(gprx_handle h);
 
+/* Form of the scaled squared distance r2 inside every kernel evaluation of this handle (kernel-matrix builds and the
+ * g / h factors of the gradient passes):
+ *   GPRX_DIST_DIFFERENCE (default)  r2 = sum_k ((a_k - b_k) / l_k)^2: no cancellation, r2(a, a) == 0 exactly;
+ *   GPRX_DIST_EXPANDED              r2 = |a/l|^2 + |b/l|^2 - 2 (a/l).(b/l): the literal arithmetic of gpflow's
+ *                                   square_distance, which the kernels constructed at gpr.py:298 evaluate.
+ * The two agree to rounding for RBF / Matern32 / Matern52; for Matern12 / Exponential (not differentiable at r = 0) the
+ * expanded form leaves r2 ~ 1e-15 on coincident points, which moves outputs by 1e-9 .. 1e-8. */
+#define GPRX_DIST_DIFFERENCE 0
+#define GPRX_DIST_EXPANDED 1
+int gprx_set_distance_form(gprx_handle h, int form);
+
 /* x: (n, d) row-major, y: (n, n_units) row-major -- the arrays GPRAS.fit stores after the
  * float64 cast (gpr.py:265-266). */
 int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units);
@@ -164,7 +175,8 @@ int gprx_memcpy_d2h(int device, void* dst_host, const void* src_dev, int64_t byt
  * a: (n1, d), b: (n2, d) device, ls: d host values (lengthscale per dimension; inputs are divided by it).
  * mode 0: all of the (n1p, n2p) padded rectangle, zero padding; mode 1: a == b, only tiles on or
  * below the diagonal are written (what the Cholesky reads); mode 2: a == b, all tiles.  Modes 1
- * and 2 pad (i >= n1 or j >= n2) with the identity. */
+ * and 2 pad (i >= n1 or j >= n2) with the identity.  mode + 4: the same with r2 in gpflow's expanded form
+ * (GPRX_DIST_EXPANDED, see gprx_set_distance_form). */
 int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const double* b_dev, int64_t n2, int d,
               const double* ls_host, double variance, double diag_add, double* out_dev, int64_t ld, int64_t n1p,
               int64_t n2p, int mode);
@@ -226,6 +238,13 @@ int gprx_metrics(int device, const double* x, const double* y, const double* con
 /* same with device-resident fields and outputs (matches is a host pointer; the call synchronises) */
 int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const double* conf_dev, int64_t rows, int64_t cells, int t_tol,
                      double v_tol, double* row_sums_dev, double* cell_sums_dev, int* cell_arg_dev, unsigned long long* matches);
+
+/* out[c] = field[idx[c], c] for a device-resident field (rows, cells): the gathers x[x_mts, np.arange(x.shape[1])] that
+ * every *_mts function of the reference performs (gpras/metrics.py:119-121, 133-135, 147-151, 167-171, 215-224, ...) when
+ * the CALLER supplies the timesteps (x_mts / y_mts), as export_metric_summary does at metrics.py:46-57.  idx: cells host
+ * values; negative values count from the end as in numpy; an index outside [-rows, rows) gives GPRX_EINVAL (numpy raises
+ * IndexError).  out: cells host values. */
+int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t cells, const int64_t* idx, double* out);
 
 /* Process-wide tuning of the Cholesky schedule; value 0 restores the default.  Keys: "panel_width" (64 | 128),
  * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update), "no_lookahead"

@@ -1,7 +1,9 @@
 """CPU restatement (test infrastructure) of the field metrics -- SURVEY.md section 8(f) row N3,
 ``/root/reference/gpras/metrics.py:85-318``.  Plain numpy in the reference too; each function follows the reference's
 expression (same reductions, same argmax / threshold conventions).  x = truth, y = prediction, both (timesteps, cells).
-PARITY UNPINNED against the real reference (it has no tests or fixtures for these functions)."""
+PINNED by outputs of the reference itself: ``tests/golden/make_golden_metrics_ref.py`` imports the reference module in the
+build container (its imports are numpy / pandas / sqlite3 only) and writes ``tests/golden/metrics_ref_golden.npz``;
+``tests/test_metrics_ref.py`` checks every function here, and ``export_metric_tables``, against it."""
 
 from __future__ import annotations
 
@@ -121,3 +123,51 @@ def f2_mts(x, y, depth_threshold=0, x_mts=None, y_mts=None):  # :263-289 (called
 def f3_mts(x, y, depth_threshold=0, x_mts=None, y_mts=None):  # :292-318
     a, b, c = contingency(x, y, depth_threshold, x_mts, y_mts)
     return 1 if a + b + c == 0 else float((a - b) / (a + b + c))
+
+
+def export_metric_tables(x_all, y_all, conf_all, depth_threshold=0.5, t_tol=0, v_tol=0, hydraulic_parameter="depth"):
+    """The three tables that ``export_metric_summary`` (metrics.py:11-82) writes to sqlite, as DataFrames
+    (scalar_metrics, timeseries_metrics, cell_metrics).  The calls are the reference's, positional quirk of :56-57 included."""
+    import pandas as pd
+
+    all_scalar, all_timeseries, all_cells = [], [], []
+    for event in x_all.index.unique(level=0):  # :26
+        x = x_all.loc[event].values
+        y = y_all.loc[event].values
+        conf = conf_all.loc[event].values
+        tsteps = x_all.loc[event].index.values
+        x_mts = np.argmax(x, axis=0)  # :35-36
+        y_mts = np.argmax(y, axis=0)
+        wet = hydraulic_parameter != "velocity"
+        all_scalar.append(pd.DataFrame.from_dict({  # :39-58
+            "event": event,
+            "rmse_aoi_toi": [rmse_aoi_toi(x, y)],
+            "mae_aoi_toi": [mae_aoi_toi(x, y)],
+            "conf_aoi_toi": [conf_aoi_toi(conf)],
+            "rmse_aoi_mts": [rmse_aoi_mts(x, y, x_mts, y_mts)],
+            "nse_aoi_mts": [nse_aoi_mts(x, y, x_mts, y_mts)],
+            "err_aoi_toi": [err_aoi_toi(x, y)],
+            "err_aoi_mts": [err_aoi_mts(x, y, x_mts, y_mts)],
+            "fi_aoi_toi": [fi_aoi_toi(x, y, t_tol, v_tol)],
+            "pod_mts": [pod_mts(x, y, depth_threshold, x_mts, y_mts)] if wet else [np.nan],
+            "rfa_mts": [rfa_mts(x, y, depth_threshold, x_mts, y_mts)] if wet else [np.nan],
+            "csi_mts": [csi_mts(x, y, depth_threshold, x_mts, y_mts)] if wet else [np.nan],
+            "f2_mts": [f2_mts(x, y, x_mts, y_mts)],  # :56: x_mts in the depth_threshold slot, y_mts in the x_mts slot
+            "f3_mts": [f3_mts(x, y, x_mts, y_mts)],  # :57
+        }))
+        all_timeseries.append(pd.DataFrame.from_dict({  # :61-68
+            "event": np.repeat(event, x.shape[0]),
+            "timestep": tsteps,
+            "rmse_aoi_ts": rmse_aoi_ts(x, y),
+            "err_aoi_ts": err_aoi_ts(x, y),
+            "conf_aoi_ts": conf_aoi_ts(conf),
+        }))
+        all_cells.append(pd.DataFrame.from_dict({  # :71-79
+            "event": np.repeat(event, x.shape[1]),
+            "cell_id": x_all.columns,
+            "rmse_cell_toi": rmse_cell_toi(x, y),
+            "err_cell_mts": err_cell_mts(x, y, x_mts, y_mts),
+            "err_cell_toi": err_cell_toi(x, y),
+            "conf_cell_toi": conf_cell_toi(conf),
+        }))
+    return pd.concat(all_scalar), pd.concat(all_timeseries), pd.concat(all_cells)

@@ -22,8 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class OracleBackend:
     """Implements the Engine interface (objective / predict / attributes) on the numpy oracle."""
 
-    def __init__(self, kernel, x, y, n_inducing=0, ard=False, device=0):
+    def __init__(self, kernel, x, y, n_inducing=0, ard=False, device=0, distance_form="difference"):
         _lib.KERNEL_IDS[kernel]
+        self.distance_form = distance_form
         self.kernel, self.x, self.y = kernel, np.asarray(x, float), np.asarray(y, float)
         self.n, self.d = self.x.shape
         self.n_units = self.y.shape[1]
