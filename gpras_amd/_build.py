@@ -11,7 +11,6 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libgprx.so"
 SOURCES = ["gprx.hip"]
-HEADERS = ["gprx_common.h", "gemm_f64.h", "kmat.h", "potrf.h", "solve.h", "grad.h", "sgpr.h"]
 
 
 def _hipcc() -> str:
@@ -25,7 +24,7 @@ def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
     built = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES + HEADERS] + [PKG_DIR.parent / "include" / "gprx.h"]
+    deps = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hip")) + [PKG_DIR.parent / "include" / "gprx.h"]  # every file gprx.hip may include
     return any(p.exists() and p.stat().st_mtime > built for p in deps)
 
 

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "gprx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "gprx_last_profile": (C.c_int, [_vp, _dp]),
     "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "gprx_mem_info": (C.c_int, [C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "gprx_cell_bytes": (C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     "gprx_dev_malloc": (C.c_int, [C.c_int, _i64, C.POINTER(_vp)]),
     "gprx_dev_free": (C.c_int, [C.c_int, _vp]),
     "gprx_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, _i64]),
@@ -73,6 +75,7 @@ PROTOTYPES = {
     "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),
     "gprx_potrf": (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _ip]),
     "gprx_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "gprx_set_handle_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "gprx_mfma_f64_peak": (C.c_int, [C.c_int, _dp]),
 }
 

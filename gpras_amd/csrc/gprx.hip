@@ -53,6 +53,8 @@ struct gprx_ctx {
   int64_t n = 0, m = 0, np = 0, mp = 0;
   int d = 0, kid = 0, ard = 0, nlen = 1, ntheta = 3, n_units = 0;
   int dist_form = 0;  // GPRX_DIST_DIFFERENCE / GPRX_DIST_EXPANDED
+  PotrfTuning tune;   // schedule knobs of this handle: the process defaults at creation, then gprx_set_handle_tuning
+  int predict_path = 0;
   std::string err;
   // data
   Buf X, Y, Z, invls, alpha, red, Kmat, invD, Xinv, Tmp, partial, xs, Ks, pred;
@@ -240,6 +242,15 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if ((rc = ensure(h, h->alpha, sizeof(double) * h->np))) return rc;
   if ((rc = ensure(h, h->dstage, sizeof(double) * h->np * STAGE_LD))) return rc;
   if (lookahead && (rc = ensure_lookahead(h))) return rc;
+  if (h->Kmat.borrowed && h->arena.p && h->cell_stride > 0) {
+    // Kmat / invD / alpha are views into a slot of the last batch (gprx_select_slot): this call overwrites that slot's
+    // factorisation, so the slot no longer holds what slot_theta / slot_unit say
+    const int64_t slot = (h->Kmat.p - h->arena.p) / h->cell_stride;
+    if (slot >= 0 && slot < (int64_t)h->slot_ok.size()) {
+      h->slot_ok[slot] = 0;
+      h->slot_unit[slot] = -1;
+    }
+  }
   hipStream_t st = h->stream;
   if (capture) {
     // replayable form: every theta-dependent value travels pinned host -> device inside the graph
@@ -258,7 +269,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
   if (h->profiling) h->prof.reset();
   HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->profiling ? &h->prof : nullptr,
-                        lookahead ? &h->pstreams : nullptr));
+                        lookahead ? &h->pstreams : nullptr, 1, 0, 0, &h->tune));
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
   hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
@@ -486,7 +497,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
     HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
-                          2 * CELL_RES));
+                          2 * CELL_RES, &h->tune));
     const double* beta = K0 + (int64_t)np * ld;
     hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
     hipLaunchKernelGGL(logdet_quad_kernel, dim3(cnt), dim3(256), 0, gs, (const double*)K0, ld, beta, np, cres, cs, CELL_RES);
@@ -590,7 +601,7 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   for (int c = 0; c < count; ++c) HIPCHK(h, hipMemsetAsync(X0 + (int64_t)c * gs, 0, sizeof(double) * h->np * ld, st));
   // 64 x 64 tiles throughout: with many cells per launch they beat the 128 x 128 tiles on these triangular products
   // (measured at 32 cells of N = 4096: 52.8 ms against 60.7 ms per batched objective + gradient)
-  const int tile = potrf_tuning().update_tile ? potrf_tuning().update_tile : 64;
+  const int tile = h->tune.update_tile ? h->tune.update_tile : 64;
   HIPCHK(h, trtri_lower(st, K0, ld, K0 + h->off_invd, X0, ld, T0, ld, np, count, cs, gs, tile));
   HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, tile, count, gs, gs,
                         gs));
@@ -636,7 +647,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   h->have_linv = true;
   // K^-1 = X^T X, lower tiles, into Tmp
   HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld,
-                        GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, potrf_tuning().update_tile));
+                        GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, h->tune.update_tile));
   const int tiles = np / KM_T;
   const int width = 2 + h->d;
   if ((rc = ensure(h, h->partial, sizeof(double) * ((size_t)tiles * tiles * width + width)))) return rc;
@@ -705,7 +716,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   HIPCHK(h, launch_kmat(st, h->kid, with_form(kq, h)));
   HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
-  HIPCHK(h, potrf_lower(st, h->Qm.p, mp, mp, 0, h->invDL.p, h->info, h->dstage.p, nullptr, nullptr));
+  HIPCHK(h, potrf_lower(st, h->Qm.p, mp, mp, 0, h->invDL.p, h->info, h->dstage.p, nullptr, nullptr, 1, 0, 0, &h->tune));
   HIPCHK(h, hipMemcpyAsync(h->Am.p, h->P.p, sizeof(double) * (size_t)mp * np, hipMemcpyDeviceToDevice, st));
   HIPCHK(h, trsm_lower_left(st, h->Qm.p, mp, h->invDL.p, h->Am.p, np, mp, np));
   // B = I + A' A'^T / s (all of it: the gradient needs the symmetric matrix)
@@ -728,7 +739,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   } else {
     HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 1.0 / s, h->Am.p, np, yu, 1, 0.0, crow, 1, 0, 64));
   }
-  HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info, h->dstage.p, nullptr, nullptr));
+  HIPCHK(h, potrf_lower(st, h->Bm.p, mp, mp, NB, h->invDB.p, h->info, h->dstage.p, nullptr, nullptr, 1, 0, 0, &h->tune));
   HIPCHK(h, hipEventRecord(h->ev[2], st));
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, (const double*)h->Bm.p, (int64_t)mp, (const double*)crow, mp, h->red.p, (int64_t)0, 0);
   HIPCHK(h, hipEventRecord(h->ev[3], st));
@@ -951,7 +962,7 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   kq.diag_const = 1;
   HIPCHK(h, launch_kmat(st, h->kid, with_form(kq, h), count));
   int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
-  HIPCHK(h, potrf_lower(st, A0 + L.oQm, mp, mp, 0, A0 + L.oInvDL, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES));
+  HIPCHK(h, potrf_lower(st, A0 + L.oQm, mp, mp, 0, A0 + L.oInvDL, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES, &h->tune));
   HIPCHK(h, hipMemcpy2DAsync(A0 + L.oAm, pitch, A0 + L.oP, pitch, sizeof(double) * (size_t)mp * np, count, hipMemcpyDeviceToDevice, st));
   HIPCHK(h, trsm_lower_left(st, A0 + L.oQm, mp, A0 + L.oInvDL, A0 + L.oAm, np, mp, np, count, ss));
   if (mp <= 512 && np >= 4 * SPLITK_CHUNK) {
@@ -974,7 +985,7 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   } else {
     HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 0.0, A0 + L.oAm, np, A0 + L.oY, 1, 0.0, crow, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss, inv_s, CELL_PAR));
   }
-  HIPCHK(h, potrf_lower(st, A0 + L.oBm, mp, mp, NB, A0 + L.oInvDB, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES));
+  HIPCHK(h, potrf_lower(st, A0 + L.oBm, mp, mp, NB, A0 + L.oInvDB, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES, &h->tune));
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, (const double*)crow, mp,
                      A0 + L.oRed, ss, (int)ss);
   // ---- gradient (sgpr_gradient) ----
@@ -1126,6 +1137,8 @@ int gprx_create(int device, int64_t n, int d, int64_t m, int kernel_id, int ard,
   h->ntheta = 2 + h->nlen;
   h->np = round_up(n, NB);
   h->mp = round_up(m, NB);
+  h->tune = potrf_tuning();  // a private copy: later gprx_set_tuning calls (process defaults) do not reach this handle
+  h->predict_path = predict_path_tuning();
   // normal priority on purpose: measured on MI355X, raised/lowered stream priorities do nothing for a single
   // cell and cut the throughput of several concurrent cells by up to 2x
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1226,6 +1239,9 @@ int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units) 
   HIPCHK(h, hipMemcpy(h->Y.p, yt.data(), sizeof(double) * yt.size(), hipMemcpyHostToDevice));
   h->n_units = n_units;
   h->factorized = false;
+  h->have_linv = false;
+  std::fill(h->slot_ok.begin(), h->slot_ok.end(), 0);  // resident batch slots were factorised from the old data
+  std::fill(h->slot_unit.begin(), h->slot_unit.end(), -1);
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
   h->graphs.clear();
   h->yy.assign(n_units, 0.0);
@@ -1444,12 +1460,22 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
     }
     return frc;
   }
+  // one cell after the other (a single cell, d > 64, or GPRX_NO_SPARSE_BATCH): same contract as the batched paths -- a cell
+  // whose matrix is not positive definite gets NaN, the others are still evaluated, the first failure is returned
+  int first_error = GPRX_OK;
   for (int i = 0; i < count; ++i) {
     rc = objective_impl(h, units[i], theta + (int64_t)i * h->ntheta, z ? z + (int64_t)i * h->m * h->d : nullptr, mask, losses + i,
                         grads ? grads + (int64_t)i * gw : nullptr);
+    if (rc == GPRX_ENOTPD) {
+      losses[i] = std::numeric_limits<double>::quiet_NaN();
+      if (grads)
+        for (int64_t k = 0; k < gw; ++k) grads[(int64_t)i * gw + k] = std::numeric_limits<double>::quiet_NaN();
+      if (!first_error) first_error = rc;
+      continue;
+    }
     if (rc) return rc;
   }
-  return GPRX_OK;
+  return first_error;
 }
 
 static constexpr int PRED_TILE = 8192;
@@ -1500,7 +1526,7 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   // Measured at N = 4096 (tools/predict_sizes.py): the substitution path costs ~1.7 ms whatever the batch (2 N / 64
   // dependent launches), the inverse path 0.9 ms for L^-1 plus 0.3 us per point -- faster for every batch size; at larger
   // N the N^3 / 3 flops of L^-1 only pay from about N / 2 points on.  predict_path (gprx_set_tuning): 1 / 2 force a path.
-  const int forced = predict_path_tuning();
+  const int forced = h->predict_path;
   const bool use_inverse = forced == 1 || (forced != 2 && (h->have_linv || h->n <= 4096 || 2 * ns >= (int64_t)h->n));
   if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile * (use_inverse ? 2 : 1)))) return rc;
   double* Vbuf = h->Ks.p + (use_inverse ? (size_t)h->np * tile : 0);
@@ -1871,6 +1897,29 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
   return GPRX_OK;
 }
 
+int gprx_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!free_bytes || !total_bytes) return fail(nullptr, GPRX_EINVAL, "null argument");
+  HIPCHK(nullptr, hipSetDevice(device));
+  size_t f = 0, t = 0;
+  HIPCHK(nullptr, hipMemGetInfo(&f, &t));
+  *free_bytes = (int64_t)f;
+  *total_bytes = (int64_t)t;
+  return GPRX_OK;
+}
+
+int gprx_cell_bytes(gprx_handle h, int with_gradient, int64_t* bytes) {
+  if (!h || !bytes) return fail(h, GPRX_EINVAL, "null argument");
+  if (h->m != 0) {
+    *bytes = (int64_t)sizeof(double) * sgpr_batch_layout(h).ss;
+    return GPRX_OK;
+  }
+  const int64_t np = h->np;
+  int64_t doubles = round_up((np + NB) * np + np * NB + np * STAGE_LD + np, 64);  // arena cell (ensure_arena)
+  if (with_gradient) doubles += 2 * np * np + (np / KM_T) * (np / KM_T) * (2 + h->d) + (2 + h->d);  // garena + trace partials
+  *bytes = (int64_t)sizeof(double) * doubles;
+  return GPRX_OK;
+}
+
 int gprx_dev_malloc(int device, int64_t bytes, void** out) {
   if (!out || bytes < 0) return fail(nullptr, GPRX_EINVAL, "bad argument");
   HIPCHK(nullptr, hipSetDevice(device));
@@ -1961,10 +2010,8 @@ int gprx_panel_stamps(unsigned long long* out64) {
 }
 #endif
 
-int gprx_set_tuning(const char* key, int value) {
-  if (!key) return fail(nullptr, GPRX_EINVAL, "null key");
-  PotrfTuning& t = potrf_tuning();
-  const std::string k(key);
+namespace {
+bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int value) {
   if (k == "panel_width" && (value == 0 || value == 64 || value == 128)) t.panel_width = value;
   else if (k == "outer_block" && value >= 0 && value % 128 == 0) t.outer_block = value;
   else if (k == "update_tile" && (value == 0 || value == 64 || value == 128)) t.update_tile = value;
@@ -1973,8 +2020,21 @@ int gprx_set_tuning(const char* key, int value) {
   else if (k == "panel_occ" && (value == 0 || value == 2 || value == 3)) t.panel_occ = value;
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
-  else if (k == "predict_path" && value >= 0 && value <= 2) predict_path_tuning() = value;
-  else return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
+  else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
+  else return false;
+  return true;
+}
+}  // namespace
+
+int gprx_set_tuning(const char* key, int value) {
+  if (!key) return fail(nullptr, GPRX_EINVAL, "null key");
+  if (!apply_tuning(potrf_tuning(), predict_path_tuning(), key, value)) return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
+  return GPRX_OK;
+}
+
+int gprx_set_handle_tuning(gprx_handle h, const char* key, int value) {
+  if (!h || !key) return fail(h, GPRX_EINVAL, "null argument");
+  if (!apply_tuning(h->tune, h->predict_path, key, value)) return fail(h, GPRX_EINVAL, "unknown tuning key or bad value");
   return GPRX_OK;
 }
 

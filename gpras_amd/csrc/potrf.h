@@ -935,7 +935,7 @@ struct PotrfStreams {
 // info words info_stride ints apart; every launch carries the cell index in blockIdx.y.
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
                               double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr, int batch = 1, int64_t cs = 0,
-                              int info_stride = 0) {
+                              int info_stride = 0, const PotrfTuning* tune_in = nullptr) {
   const double* prev_stage = nullptr;
   double* prev_dst = nullptr;
   int prev_pw = 0;
@@ -950,7 +950,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     if (prof) hipEventRecord(prof->next(), s);
   };
   const int total_rows = np + extra;
-  const PotrfTuning& tune = potrf_tuning();
+  const PotrfTuning& tune = tune_in ? *tune_in : potrf_tuning();  // a handle's own knobs, or the process defaults
   if (tune.no_lookahead) ps = nullptr;
   const int ob = tune.outer_block ? tune.outer_block : (np > 4096 ? 512 : 1024);  // measured: N=2048/4096 -> 1024, N=8192/16384 -> 512
   // panel width: 64.  128 (gprx_set_tuning) selects the 128-column kernels -- fused, or in split mode one diagonal

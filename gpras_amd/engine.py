@@ -7,11 +7,25 @@ libgprx.so is missing or a device call fails.
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import threading
 
 import numpy as np
 
 from . import _lib
 from ._lib import KERNEL_IDS, as_f64, check, ptr
+
+
+def _locked(method):
+    """A gprx handle is not thread-safe (one stream, shared staging and arenas): every call that touches it holds the
+    engine's lock, so optimiser threads that share an engine (``gpras_amd.lockstep``) serialise on it."""
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+
+    return wrapper
 
 
 class Engine:
@@ -37,6 +51,7 @@ class Engine:
         self.n_len = self.d if self.ard else 1
         self.n_theta = 2 + self.n_len
         self.device = device
+        self._lock = threading.RLock()
         self._h = C.c_void_p()
         check(self._lib.gprx_create(device, self.n, self.d, self.m, kernel_id, int(self.ard), C.byref(self._h)))
         check(self._lib.gprx_set_data(self._h, ptr(x), ptr(y), self.n_units), self._h)
@@ -44,6 +59,7 @@ class Engine:
         if distance_form != "difference":
             self.set_distance_form(distance_form)
 
+    @_locked
     def set_distance_form(self, form: str) -> None:
         """``"difference"`` (default: r2 = sum ((a - b) / l)^2) or ``"expanded"`` (gpflow's literal
         ``|a|^2 + |b|^2 - 2 a.b``) for every kernel evaluation of this engine (``gprx_set_distance_form``)."""
@@ -71,6 +87,7 @@ class Engine:
             raise ValueError(f"Z must have shape {(self.m, self.d)}, got {z.shape}")
         return z, ptr(z)
 
+    @_locked
     def objective(self, unit: int, theta, z, mask: int, want_grad: bool = True):
         """``training_loss`` and (optionally) its gradient ``[d theta | d Z]`` for one output unit."""
         theta = as_f64(theta)
@@ -85,6 +102,7 @@ class Engine:
         check(self._lib.gprx_factorize(self._h, unit, ptr(theta), zp, mask, C.byref(loss)), self._h)
         return loss.value, None
 
+    @_locked
     def factorize_batch(self, units, thetas, mask: int):
         """Exact models only: factorise ``len(units)`` cells -- cell ``i`` = output unit ``units[i]`` with
         hyperparameters ``thetas[i]`` -- by one batched launch sequence (``gprx_factorize_batch``).  Returns
@@ -94,13 +112,14 @@ class Engine:
         thetas = as_f64(thetas)
         if thetas.shape != (units.size, self.n_theta):
             raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
-        losses = np.empty(units.size)
+        losses = np.full(units.size, np.nan)
         status = np.zeros(units.size, dtype=np.int32)
         rc = self._lib.gprx_factorize_batch(self._h, units.size, ptr(units), ptr(thetas), mask, ptr(losses), ptr(status))
         if rc not in (_lib.GPRX_OK, _lib.GPRX_ENOTPD):
             check(rc, self._h)
         return losses, status == 0
 
+    @_locked
     def objective_batch(self, units, thetas, mask: int, want_grad: bool = True, zs=None):
         """``training_loss`` (and gradient ``[d theta | d Z]``) of ``len(units)`` cells by batched launches
         (``gprx_objective_batch``): exact models, or sparse models with one ``Z`` per cell in ``zs (cells, M, d)``.
@@ -115,13 +134,29 @@ class Engine:
             if zs.shape != (units.size, self.m, self.d):
                 raise ValueError(f"zs must be ({units.size}, {self.m}, {self.d})")
             zp = ptr(zs)
-        losses = np.empty(units.size)
-        grads = np.zeros((units.size, self.n_theta + self.m * self.d)) if want_grad else None
+        # (NaN, not uninitialised memory: a cell the library did not reach must never look like a valid evaluation)
+        losses = np.full(units.size, np.nan)
+        grads = np.full((units.size, self.n_theta + self.m * self.d), np.nan) if want_grad else None
         rc = self._lib.gprx_objective_batch(self._h, units.size, ptr(units), ptr(thetas), zp, mask, ptr(losses), ptr(grads) if want_grad else None)
+        if rc == _lib.GPRX_ENOMEM and units.size > 1:
+            # the batch does not fit in device memory: two half batches (values do not depend on the batch composition)
+            half = units.size // 2
+            lo = self.objective_batch(units[:half], thetas[:half], mask, want_grad, None if zs is None else zs[:half])
+            hi = self.objective_batch(units[half:], thetas[half:], mask, want_grad, None if zs is None else zs[half:])
+            return (np.concatenate([lo[0], hi[0]]), None if not want_grad else np.concatenate([lo[1], hi[1]]), np.concatenate([lo[2], hi[2]]))
         if rc not in (_lib.GPRX_OK, _lib.GPRX_ENOTPD):
             check(rc, self._h)
         return losses, grads, np.isfinite(losses)
 
+    def max_cells(self, want_grad: bool = False, reserve: float = 0.15) -> int:
+        """How many cells of a batched call fit into the free device memory (``gprx_cell_bytes`` against ``gprx_mem_info``,
+        keeping ``reserve`` of the total free for predict tiles and other handles); at least 1."""
+        nbytes, free, total = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._lib.gprx_cell_bytes(self._h, int(want_grad), C.byref(nbytes)), self._h)
+        check(self._lib.gprx_mem_info(self.device, C.byref(free), C.byref(total)))
+        return max(1, int((free.value - reserve * total.value) // max(nbytes.value, 1)))
+
+    @_locked
     def select_slot(self, slot: int):
         """Make slot ``slot`` of the last ``factorize_batch`` the current factorisation (for ``predict``)."""
         check(self._lib.gprx_select_slot(self._h, int(slot)), self._h)
@@ -131,6 +166,7 @@ class Engine:
         check(self._lib.gprx_last_batch_ms(self._h, C.byref(ms)), self._h)
         return ms.value
 
+    @_locked
     def predict(self, xs, include_noise: bool = True):
         """Mean and variance at ``xs`` for the unit factorised by the last ``objective`` call."""
         xs = as_f64(xs)

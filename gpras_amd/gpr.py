@@ -95,17 +95,22 @@ class GPRAS:
         if lockstep and not can_lockstep:
             raise ValueError("lockstep fitting needs several modes on one engine (workers=1)")
         if can_lockstep and (lockstep is None or lockstep):
+            # modes per batched launch sequence: 32, or fewer when the per-cell workspaces (kernel matrix, L^-1 and K^-1 of
+            # an exact model: 5 N^2 doubles) would not fit into the free device memory
+            per_batch = 32
+            if hasattr(self.engine, "max_cells"):
+                per_batch = max(1, min(per_batch, self.engine.max_cells(want_grad=True)))
             if optimization_method in BATCHED_OPTIMIZERS:
-                # Adam-based drivers: one host loop over all modes (rows of 2-D state arrays), 32 modes per batch
+                # Adam-based drivers: one host loop over all modes (rows of 2-D state arrays)
                 before = sum(m.n_evals for m in models)
                 stats: dict[str, int] = {"batches": 0}
-                for lo in range(0, len(models), 32):
-                    BATCHED_OPTIMIZERS[optimization_method](models[lo : lo + 32], stats=stats, **opt_kwargs)
+                for lo in range(0, len(models), per_batch):
+                    BATCHED_OPTIMIZERS[optimization_method](models[lo : lo + per_batch], stats=stats, **opt_kwargs)
                 self.lockstep_stats = {"batches": stats["batches"], "evaluations": sum(m.n_evals for m in models) - before}
                 return
             from .lockstep import fit_lockstep
 
-            self.lockstep_stats = fit_lockstep(models, opt, opt_kwargs)
+            self.lockstep_stats = fit_lockstep(models, opt, opt_kwargs, max_batch=per_batch)
             return
         if len(self.engines) == 1:
             for model in models:
@@ -182,6 +187,8 @@ class GPRAS:
             return None
         if not all(hasattr(m.backend, "factorize_batch") for m in models):
             return None
+        if x.shape[1] > 64:  # the batched kernels carry at most 64 lengthscales per cell (gprx_factorize_batch)
+            return None
         means = np.full((x.shape[0], len(self.models)), np.nan)  # columns outside `indices` stay NaN
         variances = np.full((x.shape[0], len(self.models)), np.nan)
         by_engine: dict[int, list[int]] = {}
@@ -189,15 +196,18 @@ class GPRAS:
             by_engine.setdefault(id(self.models[i].backend), []).append(i)
         for idx in by_engine.values():
             eng = self.models[idx[0]].backend
-            units = [self.models[i].unit for i in idx]
-            thetas = np.stack([self.models[i].theta() for i in idx])
-            _, ok = eng.factorize_batch(units, thetas, 0)
-            if not ok.all():
-                bad = [idx[k] for k in np.flatnonzero(~ok)]
-                raise RuntimeError(f"kernel matrix not positive definite for mode(s) {bad}")
-            for slot, i in enumerate(idx):
-                eng.select_slot(slot)
-                means[:, i], variances[:, i] = eng.predict(x, include_noise=True)
+            chunk = eng.max_cells(want_grad=False) if hasattr(eng, "max_cells") else len(idx)  # cells that fit in HBM
+            for lo in range(0, len(idx), chunk):
+                part = idx[lo : lo + chunk]
+                units = [self.models[i].unit for i in part]
+                thetas = np.stack([self.models[i].theta() for i in part])
+                _, ok = eng.factorize_batch(units, thetas, 0)
+                if not ok.all():
+                    bad = [part[k] for k in np.flatnonzero(~ok)]
+                    raise RuntimeError(f"kernel matrix not positive definite for mode(s) {bad}")
+                for slot, i in enumerate(part):
+                    eng.select_slot(slot)
+                    means[:, i], variances[:, i] = eng.predict(x, include_noise=True)
         return means, variances
 
     def to_file(self, json_path: str | Path, model_dir: str | Path | None = None) -> None:

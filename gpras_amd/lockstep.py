@@ -91,7 +91,10 @@ class LockstepBackend:
         self._evaluator = evaluator
         self._wid = wid
 
-    def __getattr__(self, name):  # n_theta, n_len, m, d, ard, x, ...
+    def __getattr__(self, name):
+        # attributes (n_theta, n_len, m, d, ard, x, ...) and the engine's other calls -- factorize_batch (batched
+        # differential evolution), predict, max_cells: those run outside the lock-step rounds, directly on the shared
+        # engine, which serialises concurrent callers on its own lock (Engine._lock: a gprx handle is not thread-safe)
         return getattr(self._engine, name)
 
     def objective(self, unit, theta, z, mask, want_grad=True):

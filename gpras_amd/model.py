@@ -182,6 +182,8 @@ class GPModel:
         thetas[:, 1:-1] = softplus_inv(ls)
         thetas[:, -1] = softplus_inv(noises - NOISE_LOWER)
         out = np.empty(count)
+        if hasattr(self.backend, "max_cells"):
+            chunk = max(1, min(chunk, self.backend.max_cells(want_grad=False)))
         for lo in range(0, count, chunk):
             hi = min(count, lo + chunk)
             losses, ok = self.backend.factorize_batch(np.full(hi - lo, self.unit, dtype=np.int32), thetas[lo:hi], self.mask)

@@ -161,6 +161,13 @@ int gprx_last_profile(gprx_handle h, double* out8);
 int gprx_objective_batch(gprx_handle h, int count, const int* units, const double* theta, const double* z, int mask,
                          double* losses, double* grads);
 
+/* Sizing of batched calls: free / total device memory, and the device bytes ONE cell of a batched call on this handle
+ * occupies (exact models: kernel matrix + staging + alpha, plus L^-1 and K^-1 when gradients are asked for; sparse models:
+ * the cell block of gprx_objective_batch).  A caller keeps count * cell_bytes below the free memory; a batch that does
+ * not fit returns GPRX_ENOMEM and may be retried with fewer cells (results do not depend on the batch composition). */
+int gprx_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
+int gprx_cell_bytes(gprx_handle h, int with_gradient, int64_t* bytes);
+
 /* ---- device memory helpers (for callers that keep inputs resident in HBM) ----------- */
 int gprx_dev_malloc(int device, int64_t bytes, void** out);
 int gprx_dev_free(int device, void* ptr);
@@ -246,7 +253,10 @@ int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const
  * IndexError).  out: cells host values. */
 int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t cells, const int64_t* idx, double* out);
 
-/* Process-wide tuning of the Cholesky schedule; value 0 restores the default.  Keys: "panel_width" (64 | 128),
+/* Tuning of the Cholesky schedule; value 0 restores the default.  gprx_set_tuning changes the PROCESS DEFAULTS: they
+ * are read by the handle-less building blocks (gprx_potrf) and COPIED into a handle when it is created, so a handle never
+ * sees a later change (handles on different host threads do not share mutable tuning state); gprx_set_handle_tuning changes
+ * one handle's copy.  Set process defaults before creating handles, from one thread.  Keys: "panel_width" (64 | 128),
  * "outer_block" (multiple of 128), "update_tile" (64 | 128: workgroup tile of the bulk trailing update), "no_lookahead"
  * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
  * "inblock" (1: right-looking K = 64 strips inside an outer block instead of recursive halving), "split_panel"
@@ -254,6 +264,7 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical.
  * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution. */
 int gprx_set_tuning(const char* key, int value);
+int gprx_set_handle_tuning(gprx_handle h, const char* key, int value);
 
 /* measured back-to-back v_mfma_f64_16x16x4_f64 rate of the whole chip, TFLOP/s */
 int gprx_mfma_f64_peak(int device, double* tflops);

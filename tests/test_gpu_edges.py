@@ -219,7 +219,7 @@ def test_both_predict_paths_agree_with_the_oracle(lib, path):
     check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["Matern32"], 0, C.byref(h)))
     check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
     try:
-        check(lib.gprx_set_tuning(b"predict_path", path))
+        check(lib.gprx_set_handle_tuning(h, b"predict_path", path), h)  # per-handle: process defaults are copied at creation
         theta = theta_of(1.2, 0.8, 0.03)
         loss = C.c_double()
         check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss)), h)
@@ -228,5 +228,4 @@ def test_both_predict_paths_agree_with_the_oracle(lib, path):
         rm, rv = oex.predict("Matern32", x, y[:, 0], 1.2, 0.8, 0.03, xs)
         assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
     finally:
-        lib.gprx_set_tuning(b"predict_path", 0)
         lib.gprx_destroy(h)

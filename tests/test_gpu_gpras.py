@@ -182,3 +182,32 @@ def test_lockstep_fit_of_sparse_models_on_the_engine():
     rmean, rvar = ref.predict(xs)
     assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean))
     assert np.max(np.abs(var - rvar) / rvar) <= 1e-8
+
+
+def test_batched_differential_evolution_of_several_modes_in_lock_step():
+    """with several modes the drivers run in lock-step threads; batched DE calls Engine.factorize_batch
+    directly from every thread on the SHARED handle.  The engine serialises those calls on its lock, so the multi-mode fit
+    must equal the serial (lockstep=False) one bit for bit -- seeded DE, deterministic batched evaluations."""
+    x, y, _ = make_regression(192, 3, n_outputs=4, n_test=0, config=12, unit=9)
+    kw = dict(popsize=4, max_iter=3, seed=3, adam_iter=2, verbose=False, batched=True)
+    a = GPRAS("RBF")
+    a.fit(x, y, None, optimization_method="diffential_evolution", **kw)  # lockstep on by default for > 1 mode
+    b = GPRAS("RBF")
+    b.fit(x, y, None, optimization_method="diffential_evolution", lockstep=False, **kw)
+    for ma, mb in zip(a.models, b.models):
+        assert ma.variance == mb.variance and ma.lengthscales == mb.lengthscales and ma.noise == mb.noise
+
+
+def test_batch_sizes_follow_the_free_device_memory():
+    """the lock-step batch and the batched predict are sized from hipMemGetInfo and the per-cell
+    footprint; an over-large batch is split instead of raising MemoryError."""
+    x, y, xs = make_regression(256, 3, n_outputs=6, n_test=20, config=12, unit=10)
+    g = GPRAS("RBF")
+    g.fit(x, y, None, optimization_method="adam", max_iter=2)
+    eng = g.engine
+    cells = eng.max_cells(want_grad=True)
+    assert cells >= 6 and eng.max_cells(want_grad=False) >= cells
+    full = g.predict(xs)
+    eng.max_cells = lambda want_grad=False, reserve=0.15: 4  # pretend only four cells fit: predict must chunk, same numbers
+    chunked = g.predict(xs)
+    assert np.array_equal(full[0], chunked[0]) and np.array_equal(full[1], chunked[1])
