@@ -31,8 +31,10 @@ GAPS = {}
 
 
 def tolerances(kernel):
-    # (loss, mean, variance) relative
-    return (1e-12, 1e-11, 1e-11) if kernel in SMOOTH else (1e-8, 1e-8, 5e-8)
+    # (loss, mean, variance) relative.  Non-smooth kernels: twice the envelope the oracle needs between its OWN two forms
+    # (tests/test_oracle.py::test_distance_forms_agree: 1e-8 / 1e-8 / 5e-8) -- two expanded implementations carry
+    # independent rounding noise on the coincident-point distances, so their difference can reach the sum.
+    return (1e-12, 1e-11, 1e-11) if kernel in SMOOTH else (2e-8, 2e-8, 1e-7)
 
 
 def device_eval(lib, kernel, x, y, z, theta, xs, form):

@@ -1,0 +1,155 @@
+"""BASELINE.json configs at their FULL sizes on the GPU, through the C ABI:
+
+* C2  N = 4096, d = 8, RBF: a 32-cell batch (the split-panel schedule the bench runs) -- every cell bit-identical to a
+      single call, sampled cells against the oracle for loss, gradient and 2000 predict points;
+* C3  Matern-5/2 ARD, N = 4096, L-BFGS-B: 5 iterations against the oracle's driver (objective 1e-7);
+* C4  N = 4096, N* = 100 000: ``gprx_predict_batch`` over several cells, sampled points against the oracle;
+* C5  N = 16384, d = 12 RBF (too large for the oracle in seconds): L L^T = K on sampled entries of the downloaded factor,
+      plus the size-independent properties (reproducible loss, gradient against central differences).
+
+The oracle needs 1-4 s per N = 4096 evaluation on the GPU box's host cores, so only sampled cells go through it."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpras_amd import _lib
+from gpras_amd._lib import DeviceBuffer, check, ptr
+from gpras_amd.gpr import GPRAS
+from gpras_amd.synth import make_regression
+from oracle import exact as oex
+from oracle import gpras_oracle
+from oracle import kernels as okn
+from oracle import transforms as otr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_n4096_32_cell_batch_loss_gradient_predict(lib):
+    n, d, cells, ns = 4096, 8, 32, 2000
+    x, y, xs = make_regression(n, d, n_outputs=cells, n_test=ns, config=2, unit=31)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+    try:
+        rng = np.random.default_rng(5)
+        base = np.array(otr.unconstrain(1.0, float(np.mean(np.abs(x))), 1.0), dtype=np.float64)
+        thetas = np.ascontiguousarray(base[None, :] + rng.uniform(-0.3, 0.3, size=(cells, 3)))
+        units = np.arange(cells, dtype=np.int32)
+        losses, grads = np.zeros(cells), np.zeros((cells, 3))
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, 7, ptr(losses), ptr(grads)), h)
+        # every cell of the batch equals the single call bit for bit (same kernels, cell index in the grid)
+        for c in (0, 7, 19, 31):
+            one, g1 = C.c_double(), np.zeros(3)
+            check(lib.gprx_objective(h, c, ptr(thetas[c]), None, 7, C.byref(one), ptr(g1)), h)
+            assert one.value == losses[c] and np.array_equal(g1, grads[c]), c
+        # sampled cells against the oracle: loss 1e-9, gradient 1e-7, predictions 1e-8
+        flosses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
+        check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(flosses), ptr(status)), h)
+        assert np.array_equal(flosses, losses) and not status.any()
+        for c in (3, 17, 30):
+            ref_loss, g = oex.loss_and_grad("RBF", x, y[:, c], float(thetas[c, 0]), float(thetas[c, 1]), float(thetas[c, 2]))
+            ref_grad = np.array([g["variance"], g["lengthscales"], g["noise"]])
+            assert abs(losses[c] - ref_loss) <= 1e-9 * abs(ref_loss), c
+            assert np.max(np.abs(grads[c] - ref_grad)) <= 1e-7 * np.max(np.abs(ref_grad)), (c, grads[c], ref_grad)
+            check(lib.gprx_select_slot(h, c), h)
+            mean, var = np.zeros(ns), np.zeros(ns)
+            check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(var), 1), h)
+            v, l, s = otr.constrain(thetas[c, 0], thetas[c, 1], thetas[c, 2])
+            rm, rv = oex.predict("RBF", x, y[:, c], float(v), float(l), float(s), xs)
+            assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)), c
+            assert np.max(np.abs(var - rv) / rv) <= 1e-8, c
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_c3_n4096_matern52_ard_lbfgs_against_the_oracle_driver():
+    n, d = 4096, 8
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=500, config=3, unit=1)
+    ours = GPRAS("Matern52")
+    ours.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=5)
+    ref = gpras_oracle.GPRASOracle("Matern52")
+    ref.fit(x, y, None, optimization_method="L-BFGS-B", ard=True, max_iter=5)
+    mo, mr = ours.models[0], ref.models[0]
+    # the same scipy routine sees objective values that agree to ~1e-13, so 5 iterations end at the same point
+    assert mo.training_loss() == pytest.approx(mr.training_loss(), rel=1e-7)
+    assert mo.variance == pytest.approx(mr.variance, rel=1e-5) and mo.noise == pytest.approx(mr.noise, rel=1e-5)
+    np.testing.assert_allclose(mo.lengthscales, mr.lengthscales, rtol=1e-5)
+    # and the device objective AT the oracle's end point is the oracle's objective
+    mo.assign(variance=mr.variance, lengthscales=mr.lengthscales, noise=mr.noise)
+    assert mo.training_loss() == pytest.approx(mr.training_loss(), rel=1e-9)
+    mean, var = ours.predict(xs)
+    rmean, rvar = ref.predict(xs)
+    assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean)) and np.max(np.abs(var - rvar) / rvar) <= 1e-8
+
+
+def test_c4_predict_batch_n4096_100k_points_sampled_against_oracle(lib):
+    n, d, cells, ns = 4096, 8, 3, 100_000
+    x, y, xs = make_regression(n, d, n_outputs=cells, n_test=ns, config=4, unit=2)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+    try:
+        par = [(1.0, 0.9, 0.3), (0.7, 1.2, 0.1), (1.6, 0.7, 0.6)]
+        thetas = np.ascontiguousarray([np.concatenate([[w[0]], np.atleast_1d(w[1]), [w[2]]]) for w in (otr.unconstrain(*p) for p in par)])
+        units = np.arange(cells, dtype=np.int32)
+        means, variances = np.zeros((cells, ns)), np.zeros((cells, ns))
+        check(lib.gprx_predict_batch(h, cells, ptr(units), ptr(thetas), None, ptr(xs), ns, ptr(means), ptr(variances), 1), h)
+        pick = np.random.default_rng(6).choice(ns, size=1500, replace=False)
+        pick[:3] = (0, 8191, ns - 1)  # first point, a tile edge (tiles of 8192 points), last point
+        for c, (v, l, s) in enumerate(par):
+            rm, rv = oex.predict("RBF", x, y[:, c], v, l, s, xs[pick])
+            assert np.max(np.abs(means[c, pick] - rm)) <= 1e-8 * np.max(np.abs(rm)), c
+            assert np.max(np.abs(variances[c, pick] - rv) / rv) <= 1e-8, c
+        assert np.all(np.isfinite(means)) and np.all(variances > 0)
+    finally:
+        lib.gprx_destroy(h)
+
+
+def test_c5_n16384_d12_rbf_factor_reproduces_k_and_gradient_matches_differences(lib):
+    n, d = 16384, 12
+    x, y, _ = make_regression(n, d, n_outputs=1, n_test=0, config=5, unit=0)
+    variance, ls, noise = 1.1, 2.6, 0.3  # (sqrt(d) scale: neighbours at r ~ 1)
+    # (i) the factor itself: K = k(X, X) + s I built and factorised by the building blocks, L downloaded, L L^T sampled
+    dx = DeviceBuffer.from_array(x)
+    dk = DeviceBuffer(8 * n * n)
+    dinv = DeviceBuffer(8 * n * 64)
+    lsv = np.full(d, ls)
+    check(lib.gprx_kmat(0, okn.KERNEL_IDS["RBF"], dx.ptr, n, dx.ptr, n, d, ptr(lsv), variance, noise, dk.ptr, n, n, n, 1))
+    info = C.c_int(0)
+    check(lib.gprx_potrf(0, dk.ptr, n, n, 0, dinv.ptr, C.byref(info)))
+    assert info.value == 0
+    L = dk.to_array((n, n))
+    rng = np.random.default_rng(8)
+    ii = rng.integers(0, n, 3000)
+    jj = (ii * rng.random(3000)).astype(np.int64)  # j <= i: the lower triangle is what the factorisation reads and writes
+    ii[:4], jj[:4] = (n - 1, n - 1, 0, 8191), (n - 1, 0, 0, 4096)
+    got = np.array([np.dot(L[i, : j + 1], L[j, : j + 1]) for i, j in zip(ii, jj)])
+    want = variance * okn.g_of_r2("RBF", np.sum(((x[ii] - x[jj]) / ls) ** 2, axis=1)) + noise * (ii == jj)
+    assert np.max(np.abs(got - want)) <= 1e-11 * (variance + noise)
+    del L
+    for b in (dx, dk, dinv):
+        b.free()
+    # (ii) the model path at the same size: reproducible loss, analytic gradient against central differences
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    try:
+        theta = np.ascontiguousarray(np.array(otr.unconstrain(variance, ls, noise), dtype=np.float64))
+        loss, again, grad = C.c_double(), C.c_double(), np.zeros(3)
+        check(lib.gprx_objective(h, 0, ptr(theta), None, 7, C.byref(loss), ptr(grad)), h)
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(again)), h)
+        assert again.value == loss.value
+        eps = 1e-4
+        for k in range(3):
+            lp, lm = C.c_double(), C.c_double()
+            tp, tm = theta.copy(), theta.copy()
+            tp[k] += eps
+            tm[k] -= eps
+            check(lib.gprx_factorize(h, 0, ptr(tp), None, 7, C.byref(lp)), h)
+            check(lib.gprx_factorize(h, 0, ptr(tm), None, 7, C.byref(lm)), h)
+            fd = (lp.value - lm.value) / (2 * eps)
+            assert abs(fd - grad[k]) <= 1e-5 * max(1.0, abs(grad[k])), (k, fd, grad[k])
+    finally:
+        lib.gprx_destroy(h)
