@@ -99,6 +99,13 @@ def main():
         dist.barrier()
     lib = _lib.load()
     device = local_rank if distributed else 0
+    comm = None
+    if distributed:
+        # the job's one data-path collective runs behind the C ABI (gprx_comm_*: RCCL loaded by libgprx.so, device-resident
+        # buffers); torch.distributed only launches the ranks, carries the 128-byte RCCL id and provides the timing barrier
+        from gpras_amd.comm import Communicator
+
+        comm = Communicator.bootstrap(device, rank, world)
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
     # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
@@ -135,6 +142,9 @@ def main():
     def fit_one():
         check(lib.gprx_factorize(h, 0, ptr(theta), None, mask, C.byref(loss)), h)
 
+    d_mine = d_all = None
+    if distributed:
+        d_mine, d_all = DeviceBuffer(8 * cells, device), DeviceBuffer(8 * cells * world, device)
     for _ in range(args.warmup):
         fit_step()
     sync_all()
@@ -142,16 +152,16 @@ def main():
     for _ in range(args.steps):
         fit_step()
     if distributed:
-        # the single collective of the job: gather every rank's results over RCCL
-        mine = torch.tensor(losses, dtype=torch.float64, device=f"cuda:{local_rank}")
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
+        # the single collective of the job: every rank's results gathered over RCCL (gprx_comm_all_gather, device buffers)
+        check(lib.gprx_memcpy_h2d(device, d_mine.ptr, ptr(losses), losses.nbytes))
+        comm.all_gather_dev(d_mine, d_all, cells)
+        comm.synchronize()
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        all_losses = d_all.to_array((world, cells))
+        assert np.array_equal(all_losses[rank], losses) and np.all(np.isfinite(all_losses))
+        elapsed = comm.max(elapsed)  # the slowest rank's time
     fits_per_s = world * cells * args.steps / elapsed
 
     result = {
@@ -173,7 +183,7 @@ def main():
             "d": DIM,
             "kernel": "RBF",
             "cells_per_gpu_per_step": cells,
-            "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end",
+            "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end (gprx_comm_all_gather, device-resident)",
         },
     }
 
@@ -487,6 +497,7 @@ def main():
 
     lib.gprx_destroy(h)
     if distributed:
+        comm.close()
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()

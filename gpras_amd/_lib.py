@@ -13,7 +13,8 @@ import numpy as np
 
 LIB_PATH = Path(__file__).resolve().parent / "libgprx.so"
 
-GPRX_OK, GPRX_EINVAL, GPRX_ENOTPD, GPRX_EHIP, GPRX_ENOMEM, GPRX_ESTATE = range(6)
+GPRX_OK, GPRX_EINVAL, GPRX_ENOTPD, GPRX_EHIP, GPRX_ENOMEM, GPRX_ESTATE, GPRX_ERCCL = range(7)
+UNIQUE_ID_BYTES = 128
 TRAIN_VARIANCE, TRAIN_LENGTHSCALE, TRAIN_NOISE, TRAIN_Z = 1, 2, 4, 8
 GEMM_C_LOWER, GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER = 1, 2, 4, 8, 16
 
@@ -54,6 +55,17 @@ PROTOTYPES = {
     "gprx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "gprx_last_profile": (C.c_int, [_vp, _dp]),
     "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "gprx_comm_unique_id": (C.c_int, [_vp]),
+    "gprx_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "gprx_comm_destroy": (C.c_int, [_vp]),
+    "gprx_comm_last_error": (C.c_char_p, [_vp]),
+    "gprx_comm_rank": (C.c_int, [_vp, _ip, _ip]),
+    "gprx_comm_all_gather": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "gprx_comm_gather": (C.c_int, [_vp, _vp, _vp, _i64, C.c_int]),
+    "gprx_comm_all_reduce_max": (C.c_int, [_vp, _vp, _i64]),
+    "gprx_comm_all_gather_host": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "gprx_comm_barrier": (C.c_int, [_vp]),
+    "gprx_comm_synchronize": (C.c_int, [_vp]),
     "gprx_mem_info": (C.c_int, [C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "gprx_cell_bytes": (C.c_int, [_vp, C.c_int, C.POINTER(_i64)]),
     "gprx_dev_malloc": (C.c_int, [C.c_int, _i64, C.POINTER(_vp)]),

@@ -1,0 +1,78 @@
+// The ONE collective of the path: independent units are sharded over ranks with no data-path
+// communication; at the end every rank's device-resident result block is gathered over RCCL (xGMI inside a node).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1: the copy the process has already loaded -- e.g. the one PyTorch ships --
+// or the ROCm one), so libgprx.so itself has no link-time dependency on it and single-GPU users never load it.
+// One communicator = one device, one private HIP stream; collectives are asynchronous on that stream and take DEVICE
+// pointers (no host bounce).  Gathering to a root uses grouped ncclSend / ncclRecv so that all inbound xGMI links of the
+// root carry traffic at once (7 links x ~153 GB/s: a ring all-gather would be bound by one link per hop).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <string>
+
+namespace gprx {
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  std::string error;
+
+  std::mutex mu;
+
+  bool load() {
+    std::lock_guard<std::mutex> guard(mu);
+    if (lib) return true;
+    error.clear();
+    // an already-loaded RCCL first (same soname as torch's bundled copy), then the search path, then ROCm's location
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+      if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib)
+      for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) {
+      error = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+      return false;
+    }
+    auto sym = [&](const char* name) -> void* {
+      void* p = dlsym(lib, name);
+      if (!p && error.empty()) error = std::string("RCCL symbol missing: ") + name;
+      return p;
+    };
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    if (!error.empty()) {
+      lib = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+
+inline RcclApi& rccl() {
+  static RcclApi api;
+  return api;
+}
+
+}  // namespace gprx

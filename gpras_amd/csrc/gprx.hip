@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.h"
 #include "gemm_f64.h"
 #include "gprx_common.h"
 #include "grad.h"
@@ -94,6 +95,15 @@ struct gprx_ctx {
   std::vector<char> slot_ok;
   double batch_ms = 0.0;  // device time of the last batch (events around the whole batch)
   hipEvent_t bev[2] = {nullptr, nullptr};
+};
+
+struct gprx_comm_ctx {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  double* scratch = nullptr;  // device staging of the host-buffer entry points
+  size_t scratch_bytes = 0;
+  std::string err;
 };
 
 struct gprx_pca_ctx {
@@ -1917,6 +1927,164 @@ int gprx_cell_bytes(gprx_handle h, int with_gradient, int64_t* bytes) {
   int64_t doubles = round_up((np + NB) * np + np * NB + np * STAGE_LD + np, 64);  // arena cell (ensure_arena)
   if (with_gradient) doubles += 2 * np * np + (np / KM_T) * (np / KM_T) * (2 + h->d) + (2 + h->d);  // garena + trace partials
   *bytes = (int64_t)sizeof(double) * doubles;
+  return GPRX_OK;
+}
+
+// ---- the one collective of the path: RCCL over xGMI -----------------------------------------
+namespace {
+int cfail(gprx_comm c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  g_err = msg;
+  return code;
+}
+#define COMMHIP(c, expr)                                                                                               \
+  do {                                                                                                                 \
+    hipError_t e_ = (expr);                                                                                            \
+    if (e_ != hipSuccess) return cfail(c, e_ == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define COMMNCCL(c, expr)                                                                                              \
+  do {                                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                                          \
+    if (r_ != ncclSuccess) return cfail(c, GPRX_ERCCL, std::string(#expr) + ": " + rccl().GetErrorString(r_));         \
+  } while (0)
+int comm_scratch(gprx_comm c, size_t bytes) {
+  if (c->scratch_bytes >= bytes) return GPRX_OK;
+  if (c->scratch) COMMHIP(c, hipFree(c->scratch));
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  COMMHIP(c, hipMalloc((void**)&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return GPRX_OK;
+}
+}  // namespace
+
+int gprx_comm_unique_id(unsigned char* id128) {
+  if (!id128) return cfail(nullptr, GPRX_EINVAL, "null argument");
+  if (!rccl().load()) return cfail(nullptr, GPRX_ERCCL, rccl().error);
+  ncclUniqueId id;
+  COMMNCCL(nullptr, rccl().GetUniqueId(&id));
+  static_assert(sizeof(id) == GPRX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id128, &id, sizeof(id));
+  return GPRX_OK;
+}
+
+int gprx_comm_init(int device, int rank, int world, const unsigned char* id128, gprx_comm* out) {
+  if (!out) return cfail(nullptr, GPRX_EINVAL, "out is null");
+  *out = nullptr;
+  if (!id128 || world <= 0 || rank < 0 || rank >= world) return cfail(nullptr, GPRX_EINVAL, "bad rank / world / id");
+  if (!rccl().load()) return cfail(nullptr, GPRX_ERCCL, rccl().error);
+  COMMHIP(nullptr, hipSetDevice(device));
+  gprx_comm c = new gprx_comm_ctx();
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return cfail(nullptr, GPRX_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);  // collective: every rank of the job calls it
+  if (r != ncclSuccess) {
+    const std::string msg = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return cfail(nullptr, GPRX_ERCCL, msg);
+  }
+  *out = c;
+  return GPRX_OK;
+}
+
+int gprx_comm_destroy(gprx_comm c) {
+  if (!c) return GPRX_OK;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->comm) rccl().CommDestroy(c->comm);
+  if (c->scratch) hipFree(c->scratch);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return GPRX_OK;
+}
+
+const char* gprx_comm_last_error(gprx_comm c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int gprx_comm_rank(gprx_comm c, int* rank, int* world) {
+  if (!c || !rank || !world) return cfail(c, GPRX_EINVAL, "null argument");
+  *rank = c->rank;
+  *world = c->world;
+  return GPRX_OK;
+}
+
+int gprx_comm_synchronize(gprx_comm c) {
+  if (!c) return cfail(c, GPRX_EINVAL, "null communicator");
+  COMMHIP(c, hipSetDevice(c->device));
+  COMMHIP(c, hipStreamSynchronize(c->stream));
+  return GPRX_OK;
+}
+
+int gprx_comm_all_gather(gprx_comm c, const double* send_dev, double* recv_dev, int64_t count) {
+  if (!c || count < 0 || (count > 0 && (!send_dev || !recv_dev))) return cfail(c, GPRX_EINVAL, "null argument");
+  if (count == 0) return GPRX_OK;
+  COMMHIP(c, hipSetDevice(c->device));
+  COMMNCCL(c, rccl().AllGather(send_dev, recv_dev, (size_t)count, ncclDouble, c->comm, c->stream));
+  return GPRX_OK;
+}
+
+int gprx_comm_gather(gprx_comm c, const double* send_dev, double* recv_dev, int64_t count, int root) {
+  if (!c || count < 0 || root < 0 || root >= c->world || (count > 0 && !send_dev)) return cfail(c, GPRX_EINVAL, "bad argument");
+  if (c->rank == root && count > 0 && !recv_dev) return cfail(c, GPRX_EINVAL, "recv_dev is null on the root");
+  if (count == 0) return GPRX_OK;
+  COMMHIP(c, hipSetDevice(c->device));
+  // one group: the root posts world - 1 receives (its own block is a device copy), every other rank one send; inside a
+  // node all inbound xGMI links of the root are busy at once
+  COMMNCCL(c, rccl().GroupStart());
+  ncclResult_t r = ncclSuccess;
+  if (c->rank == root) {
+    for (int p = 0; p < c->world && r == ncclSuccess; ++p)
+      if (p != root) r = rccl().Recv(recv_dev + (int64_t)p * count, (size_t)count, ncclDouble, p, c->comm, c->stream);
+  } else {
+    r = rccl().Send(send_dev, (size_t)count, ncclDouble, root, c->comm, c->stream);
+  }
+  const ncclResult_t r2 = rccl().GroupEnd();
+  COMMNCCL(c, r);
+  COMMNCCL(c, r2);
+  if (c->rank == root && recv_dev + (int64_t)root * count != send_dev)
+    COMMHIP(c, hipMemcpyAsync(recv_dev + (int64_t)root * count, send_dev, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+  return GPRX_OK;
+}
+
+int gprx_comm_all_reduce_max(gprx_comm c, double* buf_dev, int64_t count) {
+  if (!c || count < 0 || (count > 0 && !buf_dev)) return cfail(c, GPRX_EINVAL, "null argument");
+  if (count == 0) return GPRX_OK;
+  COMMHIP(c, hipSetDevice(c->device));
+  COMMNCCL(c, rccl().AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclMax, c->comm, c->stream));
+  return GPRX_OK;
+}
+
+int gprx_comm_all_gather_host(gprx_comm c, const double* send, double* recv, int64_t count) {
+  if (!c || count < 0 || (count > 0 && (!send || !recv))) return cfail(c, GPRX_EINVAL, "null argument");
+  if (count == 0) return GPRX_OK;
+  COMMHIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = comm_scratch(c, sizeof(double) * (size_t)count * (c->world + 1)))) return rc;
+  double* dsend = c->scratch;
+  double* drecv = c->scratch + count;
+  COMMHIP(c, hipMemcpyAsync(dsend, send, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  if ((rc = gprx_comm_all_gather(c, dsend, drecv, count))) return rc;
+  COMMHIP(c, hipMemcpyAsync(recv, drecv, sizeof(double) * count * c->world, hipMemcpyDeviceToHost, c->stream));
+  COMMHIP(c, hipStreamSynchronize(c->stream));
+  return GPRX_OK;
+}
+
+int gprx_comm_barrier(gprx_comm c) {
+  if (!c) return cfail(c, GPRX_EINVAL, "null communicator");
+  int rc;
+  COMMHIP(c, hipSetDevice(c->device));
+  if ((rc = comm_scratch(c, sizeof(double) * (size_t)(c->world + 1)))) return rc;
+  COMMHIP(c, hipMemsetAsync(c->scratch, 0, sizeof(double), c->stream));
+  if ((rc = gprx_comm_all_reduce_max(c, c->scratch, 1))) return rc;
+  COMMHIP(c, hipStreamSynchronize(c->stream));
   return GPRX_OK;
 }
 

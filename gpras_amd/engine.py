@@ -177,6 +177,18 @@ class Engine:
         check(self._lib.gprx_predict(self._h, ptr(xs), xs.shape[0], ptr(mean), ptr(var), int(include_noise)), self._h)
         return mean, var
 
+    @_locked
+    def predict_dev(self, xs_dev, ns: int, mean_dev, var_dev, include_noise: bool = True, wait: bool = True):
+        """The same with device pointers (``gprx_predict_dev``): inputs and outputs stay resident in HBM."""
+        p = lambda b: b.ptr if hasattr(b, "ptr") else b  # noqa: E731
+        check(self._lib.gprx_predict_dev(self._h, p(xs_dev), int(ns), p(mean_dev), p(var_dev), int(include_noise)), self._h)
+        if wait:
+            check(self._lib.gprx_synchronize(self._h), self._h)
+
+    @_locked
+    def synchronize(self):
+        check(self._lib.gprx_synchronize(self._h), self._h)
+
     def timings(self):
         ms = (C.c_double * 4)()
         self._lib.gprx_last_timings(self._h, ms)

@@ -2,11 +2,13 @@
 
 The reference fits and predicts its per-mode models in a serial Python loop
 (``/root/reference/gpras/gpr.py:272-274, 336-339``); the models share ``x`` and nothing else
-(SURVEY.md section 8e).  Here every rank (one process per GPU, ``torch.distributed``; backend "nccl" is
-RCCL on ROCm, "gloo" on CPU for tests) owns the units ``u`` with ``u % world == rank`` (round-robin balances
-uneven optimiser iteration counts), runs them without any communication, and ONE ``all_gather`` collects
-the results: the fitted parameters after ``fit`` (a few floats + Z per unit) and the (N*, K) mean / variance
-after ``predict``.  A single large fit does not shard (replicas only).
+(SURVEY.md section 8e).  Here every rank (one process per GPU, launched by ``torch.distributed.run``) owns the units ``u``
+with ``u % world == rank`` (round-robin balances uneven optimiser iteration counts), runs them without any communication,
+and ONE collective gathers the results: the fitted parameters after ``fit`` (a few floats + Z per unit) and the (N*, K)
+mean / variance after ``predict``.  On GPUs the collective is RCCL behind the C ABI (``gprx_comm_*``, ``gpras_amd.comm``),
+device-resident for the predictions; ``torch.distributed`` only carries the 128-byte RCCL id at start-up.  With a CPU
+process group ("gloo": the tests of this host logic) the same gather goes through ``torch.distributed``.
+A single large fit does not shard (replicas only).
 """
 
 from __future__ import annotations
@@ -32,17 +34,39 @@ def _dist():
     return dist
 
 
+_COMM = None  # this process's gprx communicator (RCCL), created on first use when the process group's backend is "nccl"
+
+
+def communicator(device: int | None = None):
+    """The RCCL communicator behind the C ABI (``gprx_comm_*``), bootstrapped through the process group (the 128-byte id
+    is broadcast from rank 0); ``None`` for CPU process groups (gloo: tests of the host logic)."""
+    global _COMM
+    dist = _dist()
+    if dist.get_backend() != "nccl":
+        return None
+    if _COMM is None:
+        import torch
+
+        from .comm import Communicator
+
+        dev = torch.cuda.current_device() if device is None else device
+        _COMM = Communicator.bootstrap(dev, dist.get_rank(), dist.get_world_size())
+    return _COMM
+
+
 def _all_gather_array(arr: np.ndarray) -> list[np.ndarray]:
-    """One collective: gather equally-shaped float64 arrays from every rank (RCCL for nccl, gloo on CPU)."""
+    """One collective: equally-shaped float64 arrays from every rank -- ``gprx_comm_all_gather_host`` (RCCL through the C
+    ABI) on GPUs, gloo on CPU (tests)."""
+    comm = communicator()
+    if comm is not None:
+        return comm.all_gather(arr)
     import torch
 
     dist = _dist()
-    backend = dist.get_backend()
-    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(device)
+    mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
-    return [t.cpu().numpy() for t in out]
+    return [t.numpy() for t in out]
 
 
 class ShardedGPRAS(GPRAS):
@@ -101,14 +125,23 @@ class ShardedGPRAS(GPRAS):
                 if zsize:
                     m.Z = vals[2 + n_len :].reshape(m.Z.shape)
 
-    def predict(self, x, sharded: bool = True):
+    def predict(self, x, sharded: bool = True, root: int | None = None):
+        """Sharded predict: every rank predicts its units, ONE collective gathers the (N*, K) mean / variance.
+        ``root=None``: every rank returns the full arrays (all-gather); ``root=r``: only rank r does (gather to the root, all
+        of its inbound xGMI links in parallel), the others return ``None``.  On GPUs the predictions stay in device memory
+        from ``gprx_predict_dev`` to the collective (``gprx_comm_all_gather`` / ``gprx_comm_gather``): no host bounce."""
         if not sharded:
             return super().predict(x)
-        x = x.astype(np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
         k = len(self.models)
         mine = shard_units(k, self.rank, self.world)
         n_max = (k + self.world - 1) // self.world
-        local = np.zeros((2, n_max, x.shape[0]))
+        ns = x.shape[0]
+        comm = communicator(self.device)
+        exact = all(m.Z is None for m in self.models)
+        if comm is not None and exact and x.shape[1] <= 64 and hasattr(self.engine, "predict_dev"):
+            return self._predict_device_resident(x, mine, n_max, comm, root)
+        local = np.zeros((2, n_max, ns))
         batched = self._predict_batched(x, mine) if mine else None  # exact models: one batched launch sequence
         for row, u in enumerate(mine):
             if batched is not None:
@@ -118,10 +151,53 @@ class ShardedGPRAS(GPRAS):
             local[0, row] = mean[:, 0]
             local[1, row] = var[:, 0]
         gathered = _all_gather_array(local)  # the single collective of predict
-        means = np.empty((x.shape[0], k))
-        variances = np.empty((x.shape[0], k))
+        return self._unpack_predictions(gathered, ns) if root is None or root == self.rank else None
+
+    def _unpack_predictions(self, gathered, ns: int):
+        k = len(self.models)
+        means = np.empty((ns, k))
+        variances = np.empty((ns, k))
         for r, block in enumerate(gathered):
             for row, u in enumerate(shard_units(k, r, self.world)):
                 means[:, u] = block[0, row]
                 variances[:, u] = block[1, row]
         return means, variances
+
+    def _predict_device_resident(self, x, mine, n_max: int, comm, root):
+        from ._lib import DeviceBuffer, check, load, ptr
+
+        eng, ns = self.engine, x.shape[0]
+        dxs = DeviceBuffer.from_array(x, self.device)
+        block = 2 * n_max * ns
+        local = DeviceBuffer(8 * block, self.device)
+        if len(mine) < n_max:  # the padding row of a ragged shard: defined values
+            zeros = np.zeros(ns)
+            for stat in range(2):
+                for row in range(len(mine), n_max):
+                    check(load().gprx_memcpy_h2d(self.device, local.at((stat * n_max + row) * ns), ptr(zeros), zeros.nbytes))
+        chunk = eng.max_cells(want_grad=False)
+        for lo in range(0, len(mine), chunk):
+            part = mine[lo : lo + chunk]
+            _, ok = eng.factorize_batch([self.models[u].unit for u in part], np.stack([self.models[u].theta() for u in part]), 0)
+            if not ok.all():
+                raise RuntimeError(f"kernel matrix not positive definite for mode(s) {[part[i] for i in np.flatnonzero(~ok)]}")
+            for slot, u in enumerate(part):
+                row = lo + slot
+                eng.select_slot(slot)
+                eng.predict_dev(dxs, ns, local.at(row * ns), local.at((n_max + row) * ns), include_noise=True, wait=False)
+        eng.synchronize()  # the predictions are complete before the communicator's stream reads them
+        gather_to_all = root is None
+        recv = DeviceBuffer(8 * block * self.world, self.device) if gather_to_all or root == self.rank else None
+        if gather_to_all:
+            comm.all_gather_dev(local, recv, block)
+        else:
+            comm.gather_dev(local, recv, block, root)
+        comm.synchronize()
+        out = None
+        if recv is not None:
+            gathered = recv.to_array((self.world, 2, n_max, ns))
+            out = self._unpack_predictions([gathered[r] for r in range(self.world)], ns)
+            recv.free()
+        dxs.free()
+        local.free()
+        return out

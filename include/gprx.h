@@ -43,6 +43,7 @@ extern "C" {
 #define GPRX_EHIP 3    /* HIP runtime error                  -> RuntimeError            */
 #define GPRX_ENOMEM 4  /* device allocation failed           -> MemoryError             */
 #define GPRX_ESTATE 5  /* call order violated (e.g. predict before factorize)           */
+#define GPRX_ERCCL 6   /* RCCL missing or a collective failed                -> RuntimeError */
 
 /* kernel ids: the five stationary kernels KERNEL_FACTORY (gpr.py:21-37) can construct
  * with kernel(variance=, lengthscales=) at gpr.py:298 */
@@ -60,6 +61,7 @@ extern "C" {
 
 typedef struct gprx_ctx* gprx_handle;
 typedef struct gprx_pca_ctx* gprx_pca_handle;
+typedef struct gprx_comm_ctx* gprx_comm;
 
 /* ---- library / device -------------------------------------------------------------- */
 int gprx_version(void);
@@ -167,6 +169,34 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
  * not fit returns GPRX_ENOMEM and may be retried with fewer cells (results do not depend on the batch composition). */
 int gprx_mem_info(int device, int64_t* free_bytes, int64_t* total_bytes);
 int gprx_cell_bytes(gprx_handle h, int with_gradient, int64_t* bytes);
+
+/* ---- multi-GPU: independent units sharded over ranks, ONE gather at the end ------------------- */
+/* The reference has no multi-device code; its unit loops (gpr.py:272-274, 336-339; restarts :87; CV configurations,
+ * cross_validation.py:61) are serial and share nothing but x.  One process per GPU: unit u -> rank u mod world, no
+ * communication during compute, and these calls for the single collective at the end.  RCCL is loaded at run time
+ * (dlopen), communicators are bound to one device and one private stream; every buffer is DEVICE memory and the calls are
+ * asynchronous on that stream (gprx_comm_synchronize waits), so results never bounce through the host.
+ *   gprx_comm_unique_id : rank 0 creates the 128-byte id (ncclGetUniqueId); the launcher distributes it (any side channel:
+ *                         torch.distributed's store, a file, MPI) -- the id is the only out-of-band datum.
+ *   gprx_comm_init      : collective over all ranks (ncclCommInitRank).
+ *   gprx_comm_all_gather: recv_dev (world * count) <- every rank's send_dev (count), rank-major (ncclAllGather).
+ *   gprx_comm_gather    : to `root` only, as grouped ncclSend / ncclRecv (all inbound xGMI links of the root at once);
+ *                         recv_dev is read on the root only.
+ *   gprx_comm_all_reduce_max: element-wise maximum in place (the slowest rank's time of a benchmark).
+ *   gprx_comm_all_gather_host: the same all-gather for small HOST buffers (fitted parameters), staged through the device;
+ *                         synchronous.   gprx_comm_barrier: all ranks have arrived (one-element all-reduce + wait). */
+#define GPRX_UNIQUE_ID_BYTES 128
+int gprx_comm_unique_id(unsigned char* id128);
+int gprx_comm_init(int device, int rank, int world, const unsigned char* id128, gprx_comm* out);
+int gprx_comm_destroy(gprx_comm c);
+const char* gprx_comm_last_error(gprx_comm c);
+int gprx_comm_rank(gprx_comm c, int* rank, int* world);
+int gprx_comm_all_gather(gprx_comm c, const double* send_dev, double* recv_dev, int64_t count);
+int gprx_comm_gather(gprx_comm c, const double* send_dev, double* recv_dev, int64_t count, int root);
+int gprx_comm_all_reduce_max(gprx_comm c, double* buf_dev, int64_t count);
+int gprx_comm_all_gather_host(gprx_comm c, const double* send, double* recv, int64_t count);
+int gprx_comm_barrier(gprx_comm c);
+int gprx_comm_synchronize(gprx_comm c);
 
 /* ---- device memory helpers (for callers that keep inputs resident in HBM) ----------- */
 int gprx_dev_malloc(int device, int64_t bytes, void** out);

@@ -30,11 +30,17 @@ SMOOTH = ("RBF", "Matern32", "Matern52")
 GAPS = {}
 
 
-def tolerances(kernel):
-    # (loss, mean, variance) relative.  Non-smooth kernels: twice the envelope the oracle needs between its OWN two forms
-    # (tests/test_oracle.py::test_distance_forms_agree: 1e-8 / 1e-8 / 5e-8) -- two expanded implementations carry
-    # independent rounding noise on the coincident-point distances, so their difference can reach the sum.
-    return (1e-12, 1e-11, 1e-11) if kernel in SMOOTH else (2e-8, 2e-8, 1e-7)
+def tolerances(kernel, form="difference"):
+    """(loss, mean, variance) relative, against oracle(form="expanded").
+    Device EXPANDED form: the kernel restates numpy's order (squares rounded and summed in k order, the dot product as an fma
+    chain in k order), so it reproduces the oracle's expanded arithmetic INCLUDING its rounding noise on coincident points:
+    measured <= 3e-15 on every output of every kernel (gpurun_out/distance_form_gaps.json).
+    Device DIFFERENCE form (default): rounding for the smooth kernels; for Matern12 / Exponential the envelope measured
+    between the two forms (sparse model: 2e-9 loss, 1e-9 mean, 1e-8 variance; exact N = 256: 3e-9, 1.2e-8, 2.5e-8), asserted
+    with a factor 2-4 of head room -- the same size the oracle shows between its own two forms."""
+    if form == "expanded" or kernel in SMOOTH:
+        return (1e-12, 1e-11, 1e-11)
+    return (1e-8, 3e-8, 1e-7)
 
 
 def device_eval(lib, kernel, x, y, z, theta, xs, form):
@@ -72,9 +78,9 @@ def test_sparse_model_both_forms_against_gpflows_arithmetic(lib, kernel):
     theta = np.ascontiguousarray([wv, wl, wn], dtype=np.float64)
     ref_loss = osg.loss(kernel, x, y[:, 0], z, float(wv), float(wl), float(wn), form="expanded")
     ref_mean, ref_var = osg.predict(kernel, x, y[:, 0], z, variance, ls, noise, xs, form="expanded")
-    tl, tm, tv = tolerances(kernel)
     out = {}
     for form in ("difference", "expanded"):
+        tl, tm, tv = tolerances(kernel, form)
         loss, grad, mean, var = device_eval(lib, kernel, x, y, z, theta, xs, form)
         out[form] = (loss, grad, mean, var)
         gl, gm, gv = abs(loss - ref_loss) / abs(ref_loss), rel(mean, ref_mean), float(np.max(np.abs(var - ref_var) / ref_var))
@@ -83,6 +89,7 @@ def test_sparse_model_both_forms_against_gpflows_arithmetic(lib, kernel):
         assert gl <= tl and gm <= tm and gv <= tv, (kernel, form, gl, gm, gv)
     # the two device forms against each other: same envelope; the hyperparameter gradient moves no more than the loss does
     a, b = out["difference"], out["expanded"]
+    tl, tm, tv = tolerances(kernel, "difference")
     assert abs(a[0] - b[0]) <= tl * abs(a[0])
     assert rel(a[2], b[2]) <= tm and float(np.max(np.abs(a[3] - b[3]) / b[3])) <= tv
     gtol = 1e-10 if kernel in SMOOTH else 1e-5
@@ -99,8 +106,8 @@ def test_exact_model_both_forms(lib, kernel):
     theta = np.ascontiguousarray([wv, wl, wn], dtype=np.float64)
     ref_loss = oex.loss(kernel, x, y[:, 0], float(wv), float(wl), float(wn), form="expanded")
     ref_mean, ref_var = oex.predict(kernel, x, y[:, 0], variance, ls, noise, xs, form="expanded")
-    tl, tm, tv = tolerances(kernel)
     for form in ("difference", "expanded"):
+        tl, tm, tv = tolerances(kernel, form)
         loss, _, mean, var = device_eval(lib, kernel, x, y, None, theta, xs, form)
         gl, gm, gv = abs(loss - ref_loss) / abs(ref_loss), rel(mean, ref_mean), float(np.max(np.abs(var - ref_var) / ref_var))
         for name, val in (("loss", gl), ("mean", gm), ("var", gv)):
