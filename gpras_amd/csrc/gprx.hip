@@ -1958,9 +1958,22 @@ int comm_scratch(gprx_comm c, size_t bytes) {
 }
 }  // namespace
 
+// RCCL is loaded only after this process has initialised HIP and seen its devices: loaded first (measured on the MI355X
+// box: ncclGetUniqueId before any HIP call) it left the process with "no ROCm-capable device is detected".
+static int comm_runtime_ready() {
+  int count = 0;
+  COMMHIP(nullptr, hipInit(0));
+  COMMHIP(nullptr, hipGetDeviceCount(&count));
+  if (count <= 0) return cfail(nullptr, GPRX_EHIP, "no device visible to this process");
+  COMMHIP(nullptr, hipFree(nullptr));  // forces the runtime (context of the current device) into existence
+  if (!rccl().load()) return cfail(nullptr, GPRX_ERCCL, rccl().error);
+  return GPRX_OK;
+}
+
 int gprx_comm_unique_id(unsigned char* id128) {
   if (!id128) return cfail(nullptr, GPRX_EINVAL, "null argument");
-  if (!rccl().load()) return cfail(nullptr, GPRX_ERCCL, rccl().error);
+  int rc0;
+  if ((rc0 = comm_runtime_ready())) return rc0;
   ncclUniqueId id;
   COMMNCCL(nullptr, rccl().GetUniqueId(&id));
   static_assert(sizeof(id) == GPRX_UNIQUE_ID_BYTES, "ncclUniqueId size");
@@ -1972,8 +1985,9 @@ int gprx_comm_init(int device, int rank, int world, const unsigned char* id128, 
   if (!out) return cfail(nullptr, GPRX_EINVAL, "out is null");
   *out = nullptr;
   if (!id128 || world <= 0 || rank < 0 || rank >= world) return cfail(nullptr, GPRX_EINVAL, "bad rank / world / id");
-  if (!rccl().load()) return cfail(nullptr, GPRX_ERCCL, rccl().error);
   COMMHIP(nullptr, hipSetDevice(device));
+  int rc0;
+  if ((rc0 = comm_runtime_ready())) return rc0;
   gprx_comm c = new gprx_comm_ctx();
   c->device = device;
   c->rank = rank;

@@ -12,13 +12,13 @@ there is no CPU path.  Extensions beyond the reference: ``n_inducing=None`` fits
 
 from __future__ import annotations
 
-import pickle
 from pathlib import Path
 from typing import Any, Literal
 
 import numpy as np
 from numpy.typing import NDArray
 
+from . import modelfile
 from ._lib import KERNEL_IDS
 from .engine import Engine
 from .model import GPModel
@@ -34,7 +34,7 @@ KernelType = Literal["Matern12", "Matern32", "Matern52", "RBF", "Linear", "Polyn
 OptimizerType = Literal["two-stage", "adam", "L-BFGS-B", "stochastic", "diffential_evolution"]
 InductionInitializerType = Literal["kmeans", "grid"]
 
-FILE_FORMAT = "gpras_amd-1"
+FILE_FORMAT = modelfile.FILE_FORMAT
 
 
 class GPRAS:
@@ -213,36 +213,22 @@ class GPRAS:
     def to_file(self, json_path: str | Path, model_dir: str | Path | None = None) -> None:
         """Serialize the trained model (gpr.py:344-366).
 
-        Same dictionary layout as the reference -- ``kernel``, ``data{x, y}``, ``n_inducing``, ``models`` with
-        gpflow's parameter-dict keys -- but the values are plain numpy arrays, so the file loads without
-        gpflow.  ``model_dir`` is accepted and ignored, as in the reference.
+        Same dictionary as the reference -- ``kernel``, ``data{x, y}``, ``n_inducing``, ``models`` with gpflow's
+        parameter-dict keys -- with plain numpy arrays as values, so the file loads without gpflow.  The container follows
+        the suffix of ``json_path`` (``gpras_amd.modelfile``): ``.npz`` (arrays + JSON metadata, no pickle), ``.json`` (text),
+        anything else a pickle of the dictionary as in the reference.  ``model_dir`` is accepted and ignored, as in the reference.
         """
-        z0 = self.models[0].Z
-        d = {
-            "format": FILE_FORMAT,
-            "kernel": self.kernel_str,
-            "data": {"x": self.x, "y": self.y},
-            "n_inducing": None if z0 is None else z0.shape[0],
-            "ard": self.ard,
-            "models": [m.parameter_dict() for m in self.models],
-        }
-        with open(json_path, mode="wb") as f:
-            pickle.dump(d, f)
+        modelfile.save(modelfile.model_dict(self), json_path)
 
     @classmethod
     def from_file(cls, json_path: str | Path, device: int = 0) -> "GPRAS":
-        """Load a model written by ``to_file`` (gpr.py:368-384): re-initialise with the cheap ``"grid"``
-        inducing points, then assign every saved parameter."""
-        with open(json_path, mode="rb") as f:
-            d = pickle.load(f)
-        if d.get("format") != FILE_FORMAT:
-            raise ValueError(
-                "not a gpras_amd model file; files written by the reference hold pickled gpflow Parameter "
-                "objects and can only be read where gpflow is installed"
-            )
-        inst = cls(d["kernel"], device=device)
-        inst.x = d["data"]["x"]
-        inst.y = d["data"]["y"]
+        """Load a model written by ``to_file`` (gpr.py:368-384): re-initialise with the cheap ``"grid"`` inducing points,
+        then assign every saved parameter.  The container is recognised by content; files written by the reference are read
+        as far as that is possible without gpflow (``gpras_amd.modelfile.load``)."""
+        d = modelfile.load(json_path)
+        inst = cls(d["kernel"], device=device, distance_form=d.get("distance_form", "difference"))
+        inst.x = np.asarray(d["data"]["x"], dtype=np.float64)
+        inst.y = np.asarray(d["data"]["y"], dtype=np.float64)
         inst._init_models(inst.x, inst.y, d["n_inducing"], "grid", d.get("ard", False))
         for ind, params in enumerate(d["models"]):
             inst.models[ind].multiple_assign(params)

@@ -88,11 +88,18 @@ class GPModel:
         }
         if self.Z is not None:
             out[".inducing_variable.Z"] = self.Z.copy()
+        # extension: the optimiser's own variables, so that a reload continues from bit-identical values (the constrained
+        # values above go through softplus and back, which costs an ulp)
+        out[".unconstrained"] = self.theta()
         return out
 
     def multiple_assign(self, params):
         """``gpflow.utilities.multiple_assign`` (gpr.py:383)."""
         self.assign(params[".kernel.variance"], params[".kernel.lengthscales"], params[".likelihood.variance"])
+        w = params.get(".unconstrained")
+        if w is not None and np.size(w) == 2 + self.w_len.size:
+            w = np.asarray(w, dtype=np.float64)
+            self.w_var, self.w_len, self.w_noise = float(w[0]), w[1:-1].copy(), float(w[-1])
         if ".inducing_variable.Z" in params and self.Z is not None:
             self.Z = params[".inducing_variable.Z"]
 
