@@ -82,6 +82,7 @@ PROTOTYPES = {
     "gprx_pca_synchronize": (C.c_int, [_vp]),
     "gprx_metrics": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "gprx_metrics_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "gprx_kmeans_lloyd": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _ip]),
     "gprx_gather_rows": (C.c_int, [C.c_int, _vp, _i64, _i64, _vp, _vp]),
     "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),
     "gprx_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int, C.c_int]),

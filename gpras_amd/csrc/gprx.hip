@@ -20,6 +20,7 @@
 #include "gprx_common.h"
 #include "grad.h"
 #include "kmat.h"
+#include "kmeans.h"
 #include "metrics.h"
 #include "pca.h"
 #include "potrf.h"
@@ -1877,6 +1878,73 @@ int gprx_metrics(int device, const double* x, const double* y, const double* con
   }
   cleanup();
   return rc;
+}
+
+// ---- k-means inducing-point initialisation: Lloyd iterations on the device ---------------
+int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* centers, int m, double tol, int max_iter, int32_t* labels,
+                      int* n_iter, int* empty) {
+  if (!x || !centers || !labels || !n_iter || !empty) return fail(nullptr, GPRX_EINVAL, "null argument");
+  if (n <= 0 || d <= 0 || d > 64 || m <= 0 || m > n || max_iter <= 0 || n > (1 << 30)) return fail(nullptr, GPRX_EINVAL, "need 0 < m <= n, 0 < d <= 64, max_iter > 0");
+  HIPCHK(nullptr, hipSetDevice(device));
+  double *dx = nullptr, *dc[2] = {nullptr, nullptr}, *dstat = nullptr;
+  int* dlab = nullptr;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)dx, (void*)dc[0], (void*)dc[1], (void*)dstat, (void*)dlab})
+      if (q) hipFree(q);
+  };
+  const size_t cb = sizeof(double) * (size_t)m * d;
+  hipError_t e = hipMalloc((void**)&dx, sizeof(double) * (size_t)n * d);
+  if (e == hipSuccess) e = hipMalloc((void**)&dc[0], cb);
+  if (e == hipSuccess) e = hipMalloc((void**)&dc[1], cb);
+  if (e == hipSuccess) e = hipMalloc((void**)&dstat, sizeof(double) * (2 + m));
+  if (e == hipSuccess) e = hipMalloc((void**)&dlab, sizeof(int) * n);
+  if (e == hipSuccess) e = hipMemcpy(dx, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dc[0], centers, cb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dlab, 0xff, sizeof(int) * n);  // labels_old = -1 (_kmeans_single_lloyd)
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(nullptr, e == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string("gprx_kmeans_lloyd staging: ") + hipGetErrorString(e));
+  }
+  std::vector<double> stat(2 + m);
+  const dim3 pgrid((unsigned)((n + 255) / 256));
+  int cur = 0, it = 0;
+  bool strict = false;
+  *empty = 0;
+  for (it = 0; it < max_iter; ++it) {
+    // one iteration of lloyd_iter_chunked_dense: labels from the current centres, then the new centres and their shifts
+    hipMemsetAsync(dstat, 0, sizeof(double) * 2, nullptr);
+    hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, nullptr, (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(m), dim3(256), 0, nullptr, (const double*)dx, (int)n, d, (const int*)dlab, (const double*)dc[cur],
+                       dc[cur ^ 1], dstat);
+    e = hipMemcpy(stat.data(), dstat, sizeof(double) * (2 + m), hipMemcpyDeviceToHost);  // synchronises
+    if (e != hipSuccess) break;
+    if (stat[1] != 0.0) {  // scikit-learn relocates empty clusters to far points; the caller falls back to it
+      *empty = 1;
+      break;
+    }
+    cur ^= 1;  // centers, centers_new = centers_new, centers
+    if (stat[0] == 0.0) {  // labels equal labels_old: strict convergence
+      strict = true;
+      ++it;
+      break;
+    }
+    double shift_tot = 0.0;
+    for (int j = 0; j < m; ++j) shift_tot += stat[2 + j];
+    if (shift_tot <= tol) {
+      ++it;
+      break;
+    }
+  }
+  if (e == hipSuccess && !*empty && !strict) {
+    // rerun the E-step so that the labels match the final centres
+    hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, nullptr, (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
+  }
+  if (e == hipSuccess) e = hipMemcpy(centers, dc[cur], cb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(labels, dlab, sizeof(int) * n, hipMemcpyDeviceToHost);
+  cleanup();
+  HIPCHK(nullptr, e);
+  *n_iter = it > max_iter ? max_iter : it;
+  return GPRX_OK;
 }
 
 int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t cells, const int64_t* idx, double* out) {

@@ -21,6 +21,7 @@ from numpy.typing import NDArray
 from . import modelfile
 from ._lib import KERNEL_IDS
 from .engine import Engine
+from .kmeans import kmeans_centers
 from .model import GPModel
 from .optimizers import BATCHED_OPTIMIZERS, OPTIMIZERS
 
@@ -151,11 +152,9 @@ class GPRAS:
     def _create_inducing(self, x: NDArray[Any], n_inducing: int, method: InductionInitializerType) -> NDArray[Any]:
         """Create an array representing locations in dataspace (gpr.py:310-320)."""
         if method == "kmeans":
-            from sklearn.cluster import KMeans
-
-            km = KMeans(n_clusters=n_inducing, random_state=0, n_init="auto")
-            km.fit(x)
-            return np.ascontiguousarray(km.cluster_centers_.astype(np.float64))
+            # KMeans(n_clusters=n_inducing, random_state=0, n_init="auto").fit(x).cluster_centers_ (gpr.py:313-315): seeding on
+            # the host as scikit-learn draws it, Lloyd iterations on the device (gpras_amd.kmeans)
+            return kmeans_centers(x, n_inducing, device=self.device)
         elif method == "grid":
             inducing_variable = np.c_[np.linspace(x[:, 0].min(), x[:, 0].max(), n_inducing)]
             for j in range(1, x.shape[1]):

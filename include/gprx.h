@@ -276,6 +276,17 @@ int gprx_metrics(int device, const double* x, const double* y, const double* con
 int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const double* conf_dev, int64_t rows, int64_t cells, int t_tol,
                      double v_tol, double* row_sums_dev, double* cell_sums_dev, int* cell_arg_dev, unsigned long long* matches);
 
+/* ---- k-means inducing-point initialisation: SURVEY.md section 8(f) row N4 (gpras/gpr.py:312-315) ---------------------- */
+/* The Lloyd iterations of KMeans(n_clusters=M, random_state=0, n_init="auto").fit(x) (scikit-learn's
+ * _kmeans_single_lloyd) on the device.  x: (n, d) host, already centred (KMeans subtracts the column means); centers: (m, d)
+ * host, in: the k-means++ seeding (host: sklearn.cluster.kmeans_plusplus on RandomState(0), as KMeans draws it), out: the
+ * final centres (still centred); tol: absolute (mean(var(x)) * 1e-4); labels: n values out; n_iter: iterations run.
+ * Stops like scikit-learn: labels repeat (strict convergence) or sum of squared centre shifts <= tol, at most max_iter.
+ * *empty = 1 when a cluster lost all members (scikit-learn relocates it; centres / labels are then undefined and the
+ * caller falls back to scikit-learn).  d <= 64. */
+int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* centers, int m, double tol, int max_iter, int32_t* labels,
+                      int* n_iter, int* empty);
+
 /* out[c] = field[idx[c], c] for a device-resident field (rows, cells): the gathers x[x_mts, np.arange(x.shape[1])] that
  * every *_mts function of the reference performs (gpras/metrics.py:119-121, 133-135, 147-151, 167-171, 215-224, ...) when
  * the CALLER supplies the timesteps (x_mts / y_mts), as export_metric_summary does at metrics.py:46-57.  idx: cells host

@@ -35,3 +35,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _host_logic_kmeans(monkeypatch):
+    """CPU container only: tests of the host logic replace the HIP engine by an oracle-backed stand-in (test_host_logic.py);
+    the device Lloyd iterations of the k-means initialisation get the oracle's restatement the same way.  On a GPU box
+    nothing is patched: every test runs the real device path."""
+    if _gpu_present():
+        return
+    from gpras_amd import gpr
+    from oracle import kmeans as okm
+
+    monkeypatch.setattr(gpr, "kmeans_centers", lambda x, m, device=0: okm.kmeans_centers(x, m)[0])

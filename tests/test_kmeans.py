@@ -1,0 +1,55 @@
+"""Row N4: the k-means inducing-point initialisation of ``/root/reference/gpras/gpr.py:312-315``.
+CPU: the oracle's restatement of scikit-learn's Lloyd loop against ``KMeans`` itself (the reference's call).
+GPU: the device Lloyd iterations (``gprx_kmeans_lloyd``) against the same ``KMeans`` call, centres <= 1e-12."""
+
+import numpy as np
+import pytest
+from sklearn.cluster import KMeans
+
+from gpras_amd.synth import make_hydrograph_features, make_regression
+from oracle import kmeans as okm
+
+CASES = [(256, 4, 32, "reg"), (1000, 8, 50, "reg"), (4096, 10, 50, "reg"), (1500, 10, 300, "reg"), (700, 3, 20, "hydro"), (64, 2, 1, "reg")]
+
+
+def data(n, d, kind):
+    if kind == "hydro":
+        return make_hydrograph_features(n, d, n_outputs=1, config=1, unit=n)[0]
+    return make_regression(n, d, n_outputs=1, n_test=0, config=8, unit=n)[0]
+
+
+def reference_centers(x, m):
+    km = KMeans(n_clusters=m, random_state=0, n_init="auto").fit(x)  # gpr.py:313
+    return km.cluster_centers_, km.labels_, km.n_iter_
+
+
+@pytest.mark.parametrize("n,d,m,kind", CASES)
+def test_oracle_lloyd_reproduces_sklearn(n, d, m, kind):
+    x = data(n, d, kind)
+    want, labels, n_iter = reference_centers(x, m)
+    got, glabels, giter = okm.kmeans_centers(x, m)
+    assert giter == n_iter and np.array_equal(glabels, labels)
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,m,kind", CASES + [(16384, 12, 300, "reg")])
+def test_device_lloyd_reproduces_sklearn(n, d, m, kind):
+    from gpras_amd.kmeans import kmeans_centers
+
+    x = data(n, d, kind)
+    want, labels, n_iter = reference_centers(x, m)
+    got, info = kmeans_centers(x, m, return_info=True)
+    assert info["device"] and info["n_iter"] == n_iter and np.array_equal(info["labels"], labels)
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
+@pytest.mark.gpu
+def test_gpras_inducing_points_come_from_the_device_kmeans():
+    from gpras_amd.gpr import GPRAS
+
+    x, y, _ = make_regression(600, 5, n_outputs=1, n_test=0, config=8, unit=3)
+    g = GPRAS("RBF")
+    z = g._create_inducing(x, 40, "kmeans")
+    want, _, _ = reference_centers(x, 40)
+    assert z.shape == (40, 5) and np.max(np.abs(z - want)) <= 1e-12
