@@ -36,12 +36,29 @@ struct RcclApi {
     std::lock_guard<std::mutex> guard(mu);
     if (lib) return true;
     error.clear();
-    // an already-loaded RCCL first (same soname as torch's bundled copy), then the search path, then ROCm's location
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // (1) an RCCL this process has already loaded (e.g. PyTorch's: then the HIP runtime in use is PyTorch's too);
+    // (2) the RCCL that sits NEXT TO the HIP runtime this library is bound to -- one ROCm tree for HIP, HSA and RCCL.
+    //     Measured on the MI355X box: libgprx bound to /opt/rocm's HIP + the RCCL found first on the search path (the
+    //     copy PyTorch ships) fails in ncclCommInitRank ("pfn_hsa_system_get_info failed with 4107"): that RCCL opens its
+    //     own second copy of the HSA runtime, which nobody initialised;
+    // (3) the default search path.
+    const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* n : names)
       if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib) {
+      Dl_info info;
+      if (dladdr(reinterpret_cast<void*>(&hipInit), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+          dir.resize(slash + 1);
+          for (const char* n : names)
+            if ((lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+        }
+      }
+    }
     if (!lib)
-      for (const char* n : names)
+      for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!lib) {
       error = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");

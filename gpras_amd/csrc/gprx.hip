@@ -688,6 +688,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
 //   B = I + A' A'^T / s -> LB, c = LB^-1 A' y / s (carried through the Cholesky as an appended row).
 // SM holds nine mp x mp scratch matrices.
 constexpr int SPLITK_CHUNK = 256;
+constexpr int SGPR_PRED_TILE = 4096;  // test points per pass of the batched sparse predict
 enum { SM_BFULL = 0, SM_LINV, SM_LBINV, SM_QINV, SM_SINV, SM_R, SM_T1, SM_T2, SM_W, SM_GQ, SM_COUNT };
 
 double* sm(gprx_handle h, int slot) { return h->SM.p + (size_t)slot * h->mp * h->mp; }
@@ -867,7 +868,7 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
 // cell-parameter table.  Same kernels, same per-element operation order as sgpr_factorize / sgpr_gradient:
 // bit-identical values.
 struct SgprLayout {
-  int64_t oZ, oY, oP, oAm, oQm, oBm, oInvDL, oInvDB, oSM, oWP, oWHP, oWHQ, oVecs, odZ, oStage, oPart, oWs, oRed, ss;
+  int64_t oZ, oY, oP, oAm, oQm, oBm, oInvDL, oInvDB, oSM, oWP, oWHP, oWHQ, oVecs, odZ, oStage, oPart, oWs, oRed, oKs, oPred, ss;
   int64_t part_p, part_q;
   int width, nsplit;
 };
@@ -903,6 +904,8 @@ SgprLayout sgpr_batch_layout(gprx_handle h) {
   L.oPart = take(L.part_p + L.part_q + 2 * L.width);
   L.oWs = take((int64_t)L.nsplit * mp * mp);
   L.oRed = take(8);
+  L.oKs = take(mp * SGPR_PRED_TILE);                                           // batched predict: Kus tile of this cell
+  L.oPred = take(((mp + 255) / 256) * (int64_t)SGPR_PRED_TILE);                // its column-reduction partials
   L.ss = o;
   return L;
 }
@@ -1106,6 +1109,49 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     if (gz) std::memcpy(gz + (size_t)c * m * d, hdz + (size_t)c * m * d, sizeof(double) * m * d);
   }
   return first_error;
+}
+
+// SGPR.predict_y for every cell of the batch that sgpr_objective_batch has just factorised (its cell blocks hold L, invDL, LB,
+// invDB and c): the nine small launches of one model's predict serve all cells -- Kus per cell (own Z and hyperparameters),
+// tmp1 = L^-1 Kus, tmp2 = LB^-1 tmp1, mean = tmp2^T c, var = v + colsum(tmp2^2) - colsum(tmp1^2) (+ s).  Same kernels and
+// operation order as gprx_predict_dev on each cell: bit-identical values.  means / vars: (count, ns) device, row-major.
+int sgpr_predict_batch(gprx_handle h, int count, const double* xs_dev, int64_t ns, double* means_dev, double* vars_dev, int include_noise) {
+  const SgprLayout L = sgpr_batch_layout(h);
+  const int mp = (int)h->mp, m = (int)h->m;
+  const int64_t ss = L.ss;
+  hipStream_t st = h->stream;
+  double* A0 = h->sarena.p;
+  const double* cpar = h->cellpar.p;
+  const int rows_per_chunk = 256;
+  const int nchunks = (mp + rows_per_chunk - 1) / rows_per_chunk;
+  const int tile = SGPR_PRED_TILE;
+  const double* cvec = A0 + L.oBm + (int64_t)mp * mp;
+  for (int64_t t0 = 0; t0 < ns; t0 += tile) {
+    const int ts = (int)std::min<int64_t>(tile, ns - t0);
+    const int tsp = (int)round_up(ts, NB);
+    KmatArgs ka{A0 + L.oZ, xs_dev + t0 * h->d, nullptr, A0 + L.oKs, tile, m, ts, h->d, mp, tsp, 0.0, 0.0, 0, 0.0, nullptr, 0};
+    ka.cell_par = cpar;
+    ka.out_stride = ss;
+    ka.a_stride = ss;
+    ka.diag_const = 1;
+    HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h), count));
+    const dim3 pgrid((ts + 255) / 256, nchunks, count), fgrid((ts + 255) / 256, count);
+    HIPCHK(h, trsm_lower_left(st, A0 + L.oQm, mp, A0 + L.oInvDL, A0 + L.oKs, tile, mp, tsp, count, ss));
+    hipLaunchKernelGGL(colreduce_partial, pgrid, dim3(256), 0, st, (const double*)(A0 + L.oKs), (int64_t)tile, (const double*)nullptr, mp, ts,
+                       rows_per_chunk, A0 + L.oPred, ss, (int64_t)0, ss);
+    // var = (v [+ s]) - colsum(tmp1^2): per-cell base from the parameter table ([0] variance, [1] noise)
+    hipLaunchKernelGGL(colreduce_final, fgrid, dim3(256), 0, st, (const double*)(A0 + L.oPred), nchunks, ts, 0.0, -1.0, 0, vars_dev + t0, ss, ns, cpar,
+                       include_noise ? cpar + 1 : (const double*)nullptr, CELL_PAR);
+    HIPCHK(h, trsm_lower_left(st, A0 + L.oBm, mp, A0 + L.oInvDB, A0 + L.oKs, tile, mp, tsp, count, ss));
+    hipLaunchKernelGGL(colreduce_partial, pgrid, dim3(256), 0, st, (const double*)(A0 + L.oKs), (int64_t)tile, cvec, mp, ts, rows_per_chunk,
+                       A0 + L.oPred, ss, ss, ss);
+    hipLaunchKernelGGL(colreduce_final, fgrid, dim3(256), 0, st, (const double*)(A0 + L.oPred), nchunks, ts, 0.0, 1.0, 0, means_dev + t0, ss, ns);
+    hipLaunchKernelGGL(colreduce_partial, pgrid, dim3(256), 0, st, (const double*)(A0 + L.oKs), (int64_t)tile, (const double*)nullptr, mp, ts,
+                       rows_per_chunk, A0 + L.oPred, ss, (int64_t)0, ss);
+    hipLaunchKernelGGL(colreduce_final, fgrid, dim3(256), 0, st, (const double*)(A0 + L.oPred), nchunks, ts, 0.0, 1.0, 1, vars_dev + t0, ss, ns);
+  }
+  HIPCHK(h, hipGetLastError());
+  return GPRX_OK;
 }
 
 int check_handle(gprx_handle h) {
@@ -1617,6 +1663,35 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
       if ((rc = select_slot(h, i))) return rc;
       if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
     }
+    return GPRX_OK;
+  }
+  static const bool no_sparse_batch = getenv("GPRX_NO_SPARSE_BATCH") != nullptr;
+  if (h->m != 0 && count > 1 && h->d <= CELL_PAR - CELL_PAR_LS && !no_sparse_batch) {
+    // sparse models (what gpras runs): every cell factorised by ONE batched launch sequence, then one batched predict
+    if (!z) return fail(h, GPRX_EINVAL, "z (inducing inputs) is null for a sparse model");
+    const int64_t nz = h->m * h->d;
+    for (int64_t e = 0; e < (int64_t)count * nz; ++e)
+      if (!std::isfinite(z[e])) return fail(h, GPRX_EINVAL, "z is not finite");
+    std::vector<Theta> ts(count);
+    for (int i = 0; i < count; ++i) {
+      if (units[i] < 0 || units[i] >= h->n_units) return fail(h, GPRX_EINVAL, "unit out of range (call gprx_set_data first)");
+      for (int k = 0; k < h->ntheta; ++k)
+        if (!std::isfinite(thetas[(int64_t)i * h->ntheta + k])) return fail(h, GPRX_EINVAL, "theta is not finite");
+      ts[i] = decode_theta(h, thetas + (int64_t)i * h->ntheta);
+    }
+    std::vector<double> elbo(count);
+    std::vector<int> stv(count);
+    if ((rc = sgpr_objective_batch(h, count, units, ts.data(), z, elbo.data(), nullptr, nullptr, stv.data()))) return rc;  // ENOTPD included
+    if (ns == 0) return GPRX_OK;
+    if ((rc = ensure(h, h->xs, sizeof(double) * (ns * h->d + 2 * ns * count)))) return rc;
+    double* dxs = h->xs.p;
+    double* dmean = dxs + ns * h->d;
+    double* dvar = dmean + ns * count;
+    HIPCHK(h, hipMemcpyAsync(dxs, xs, sizeof(double) * ns * h->d, hipMemcpyHostToDevice, h->stream));
+    if ((rc = sgpr_predict_batch(h, count, dxs, ns, dmean, dvar, include_noise))) return rc;
+    HIPCHK(h, hipMemcpyAsync(means, dmean, sizeof(double) * ns * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(vars, dvar, sizeof(double) * ns * count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return GPRX_OK;
   }
   for (int i = 0; i < count; ++i) {

@@ -228,8 +228,13 @@ __global__ __launch_bounds__(256) void logdet_quad_kernel(const double* __restri
 
 // partial[chunk][t] = sum over the chunk's rows of  w[row] * M[row, t]   (w != null)
 //                                             or  M[row, t]^2            (w == null)
+// (batched: blockIdx.z = cell; M, w and partial advance by their per-cell strides)
 __global__ __launch_bounds__(256) void colreduce_partial(const double* __restrict__ M, int64_t ldm, const double* __restrict__ w, int nrows,
-                                                         int ncols, int rows_per_chunk, double* __restrict__ partial) {
+                                                         int ncols, int rows_per_chunk, double* __restrict__ partial, int64_t m_cell = 0,
+                                                         int64_t w_cell = 0, int64_t p_cell = 0) {
+  M += (int64_t)blockIdx.z * m_cell;
+  if (w) w += (int64_t)blockIdx.z * w_cell;
+  partial += (int64_t)blockIdx.z * p_cell;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ncols) return;
   const int r0 = blockIdx.y * rows_per_chunk;
@@ -257,8 +262,17 @@ __global__ __launch_bounds__(256) void colreduce_partial(const double* __restric
 }
 
 // out[t] = (accumulate ? out[t] : base) + scale * sum_chunks partial[chunk][t]
+// (batched: blockIdx.y = cell; base = base_tab[cell * base_stride] + (base_tab2 ? base_tab2[cell * base_stride] : 0) when given)
 __global__ __launch_bounds__(256) void colreduce_final(const double* __restrict__ partial, int nchunks, int ncols, double base, double scale,
-                                                       int accumulate, double* __restrict__ out) {
+                                                       int accumulate, double* __restrict__ out, int64_t p_cell = 0, int64_t out_cell = 0,
+                                                       const double* __restrict__ base_tab = nullptr, const double* __restrict__ base_tab2 = nullptr,
+                                                       int base_stride = 0) {
+  partial += (int64_t)blockIdx.y * p_cell;
+  out += (int64_t)blockIdx.y * out_cell;
+  if (base_tab) {
+    base = base_tab[(int64_t)blockIdx.y * base_stride];
+    if (base_tab2) base += base_tab2[(int64_t)blockIdx.y * base_stride];
+  }
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= ncols) return;
   double s = 0.0;

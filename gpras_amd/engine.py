@@ -178,6 +178,30 @@ class Engine:
         return mean, var
 
     @_locked
+    def predict_batch(self, units, thetas, xs, zs=None, include_noise: bool = True):
+        """The whole predict loop of gpr.py:336-339 in one call (``gprx_predict_batch``): cell ``i`` = (``units[i]``,
+        ``thetas[i]``, ``zs[i]`` for sparse models) is factorised -- all cells by one batched launch sequence -- and predicts at
+        the shared ``xs``.  Returns ``(means, variances)``, each ``(cells, N*)``."""
+        units = np.ascontiguousarray(units, dtype=np.int32)
+        thetas = as_f64(thetas)
+        xs = as_f64(xs)
+        if thetas.shape != (units.size, self.n_theta):
+            raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
+        if xs.ndim != 2 or xs.shape[1] != self.d:
+            raise ValueError(f"x must be (N*, {self.d})")
+        zp = None
+        if self.m != 0:
+            zs = as_f64(zs)
+            if zs.shape != (units.size, self.m, self.d):
+                raise ValueError(f"zs must be ({units.size}, {self.m}, {self.d})")
+            zp = ptr(zs)
+        means = np.empty((units.size, xs.shape[0]))
+        variances = np.empty((units.size, xs.shape[0]))
+        check(self._lib.gprx_predict_batch(self._h, units.size, ptr(units), ptr(thetas), zp, ptr(xs), xs.shape[0], ptr(means), ptr(variances),
+                                           int(include_noise)), self._h)
+        return means, variances
+
+    @_locked
     def predict_dev(self, xs_dev, ns: int, mean_dev, var_dev, include_noise: bool = True, wait: bool = True):
         """The same with device pointers (``gprx_predict_dev``): inputs and outputs stay resident in HBM."""
         p = lambda b: b.ptr if hasattr(b, "ptr") else b  # noqa: E731

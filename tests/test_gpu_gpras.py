@@ -211,3 +211,19 @@ def test_batch_sizes_follow_the_free_device_memory():
     eng.max_cells = lambda want_grad=False, reserve=0.15: 4  # pretend only four cells fit: predict must chunk, same numbers
     chunked = g.predict(xs)
     assert np.array_equal(full[0], chunked[0]) and np.array_equal(full[1], chunked[1])
+
+
+def test_sparse_predict_is_batched_and_equals_the_per_mode_loop():
+    """GPRAS.predict on sparse models goes through gprx_predict_batch; the reference-shaped loop over model.predict_y gives the
+    same numbers bit for bit."""
+    x, y, xs = make_regression(400, 4, n_outputs=6, n_test=300, config=14, unit=2)
+    g = GPRAS("Matern52")
+    g.fit(x, y, 24, "kmeans", "adam", max_iter=4)
+    mean, var = g.predict(xs)
+    loop = [m.predict_y(xs) for m in g.models]
+    assert np.array_equal(mean, np.concatenate([p[0] for p in loop], axis=1))
+    assert np.array_equal(var, np.concatenate([p[1] for p in loop], axis=1))
+    ref = gpras_oracle.GPRASOracle("Matern52")
+    ref.fit(x, y, 24, "kmeans", "adam", max_iter=4)
+    rmean, rvar = ref.predict(xs)
+    assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean)) and np.max(np.abs(var - rvar) / rvar) <= 1e-8

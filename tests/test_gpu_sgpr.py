@@ -184,3 +184,37 @@ def test_sparse_objective_batch_equals_single_calls(lib, kernel, n, d, m, ard, c
             assert single.value == l2[c]
     finally:
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("kernel,n,d,m,ns", [("RBF", 900, 6, 50, 5000), ("Matern32", 500, 3, 130, 700)])
+def test_batched_sparse_predict_equals_single_calls_and_oracle(lib, kernel, n, d, m, ns):
+    """``gprx_predict_batch`` on sparse models (what gpras runs, gpr.py:336-339): all cells factorised and predicted by batched
+    launches -- bit-identical to factorise + predict per cell, and within 1e-8 of the oracle.  ns > 4096 crosses a predict tile."""
+    cells = 5
+    x, y, xs = make_regression(n, d, n_outputs=cells, n_test=ns, config=13, unit=m)
+    rng = np.random.default_rng(m)
+    h = make_handle(lib, n, d, m, kernel, False, x, y)
+    try:
+        zs = np.ascontiguousarray(np.stack([gpras_oracle.create_inducing(x, m, "kmeans") + 0.01 * rng.standard_normal((m, d)) for _ in range(cells)]))
+        par = [(1.0 + 0.1 * c, 0.8 + 0.05 * c, 0.05 + 0.02 * c) for c in range(cells)]
+        thetas = np.ascontiguousarray([np.concatenate([np.atleast_1d(w) for w in otr.unconstrain(*p)]) for p in par])
+        units = np.arange(cells, dtype=np.int32)[::-1].copy()  # cell i is unit cells - 1 - i: the unit table is honoured
+        means, variances = np.zeros((cells, ns)), np.zeros((cells, ns))
+        check(lib.gprx_predict_batch(h, cells, ptr(units), ptr(thetas), ptr(zs), ptr(xs), ns, ptr(means), ptr(variances), 1), h)
+        for c in range(cells):
+            loss = C.c_double()
+            check(lib.gprx_factorize(h, int(units[c]), ptr(thetas[c]), ptr(zs[c]), 0, C.byref(loss)), h)
+            mean, var = np.zeros(ns), np.zeros(ns)
+            check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(var), 1), h)
+            assert np.array_equal(mean, means[c]) and np.array_equal(var, variances[c]), c
+            v, l, s = par[c]
+            rm, rv = osg.predict(kernel, x, y[:, units[c]], zs[c], v, l, s, xs)
+            assert np.max(np.abs(means[c] - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(variances[c] - rv) / rv) <= 1e-8
+        # latent variance (include_noise = 0) differs from the observation variance by the cell's noise
+        lat_m, lat_v = np.zeros((cells, ns)), np.zeros((cells, ns))
+        check(lib.gprx_predict_batch(h, cells, ptr(units), ptr(thetas), ptr(zs), ptr(xs), ns, ptr(lat_m), ptr(lat_v), 0), h)
+        assert np.array_equal(lat_m, means)
+        for c in range(cells):
+            np.testing.assert_allclose(variances[c] - lat_v[c], par[c][2], rtol=1e-9)
+    finally:
+        lib.gprx_destroy(h)
