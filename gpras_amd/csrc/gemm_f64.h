@@ -49,6 +49,9 @@ struct GemmArgs {
   int alpha_stride = 0;
 };
 
+#ifndef GPRX_GEMM_DMA_DEFAULT
+#define GPRX_GEMM_DMA_DEFAULT 0
+#endif
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LDK = GEMM_BK;  // KC image row stride (doubles): 128 B, unpadded; the eight 16-B chunks of a row are XOR-swizzled
 // Swizzle of the KC image: chunk c of row `row` is stored at chunk c ^ kc_swz(row).  ds_read_b128 serves a wave in four
@@ -122,8 +125,16 @@ __device__ __forceinline__ void store_mc(double* s, const d2 (&r)[COLS / 32], in
 // i.e. one workgroup of occupancy, so long-K launches use PF = 0)
 // AXF: the A operand is transformed element-wise on its way from memory to LDS (fused centring / weighting of the EOF
 // projection, pca.h): no separate pass over A.
-template <int TA, int TB, int BM, int BN, int PF = 0, int AXF = 0>
+// DMA: both operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass; the XOR
+// swizzle of the KC image moves to the per-lane SOURCE address, the LDS image is written lane-linear: 1 KiB = 8 rows of
+// 128 B per wave-instruction).  Only for the NT form on full tiles (M % BM == 0, N % BN == 0): no bounds predicates exist.
+__device__ __forceinline__ void glds16(const double* src, double* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TA, int TB, int BM, int BN, int PF = 0, int AXF = 0, int DMA = 0>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : ((PF || AXF) ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
+  static_assert(!DMA || (TA == 0 && TB == 1 && AXF == 0), "the LDS-DMA staging exists for the NT form only");
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
   constexpr int B_ELEMS = TB ? BN * GEMM_LDK : GEMM_BK * McStride<BN>::value;
@@ -350,7 +361,63 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : ((PF || AXF) ? 3 
     if (more) sstore(buf ^ 1);
     __syncthreads();
   };
-  if (kbeg < kend) {
+  if constexpr (DMA != 0) {
+    // every wave fills rows 8 (4 i + wave) .. + 7 of each operand image per instruction i; lane l: row + (l >> 3), LDS chunk
+    // l & 7, which holds the global chunk (l & 7) ^ kc_swz(row) -- the same involution the fragment reads apply
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_fill = [&](int k0, int buf) {
+      double* sa = smem + buf * (A_ELEMS + B_ELEMS);
+      double* sb = sa + A_ELEMS;
+#pragma unroll
+      for (int i = 0; i < BM / 32; ++i) {
+        const int rbase = (i * 4 + wave_u) * 8;
+        const int row = rbase + (lane >> 3);
+        glds16(p.A + (int64_t)(m0 + row) * p.lda + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sa + rbase * GEMM_LDK);
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) {
+        const int rbase = (i * 4 + wave_u) * 8;
+        const int row = rbase + (lane >> 3);
+        glds16(p.B + (int64_t)(n0 + row) * p.ldb + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sb + rbase * GEMM_LDK);
+      }
+    };
+    const int swz_d = kc_swz(r);
+    auto dma_stage = [&](int k0, int buf) {
+      if (k0 + GEMM_BK < kend) dma_fill(k0 + GEMM_BK, buf ^ 1);  // (all waves left buffer buf ^ 1 at the previous barrier)
+      const double* sa = smem + buf * (A_ELEMS + B_ELEMS);
+      const double* sb = sa + A_ELEMS;
+      double fa[TM][4], fb[TN][4];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int row = wm * (BM / 2) + a * 16 + r;
+        const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 2 * ((2 * g) ^ swz_d));
+        const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 2 * ((2 * g + 1) ^ swz_d));
+        fa[a][0] = lo.x; fa[a][1] = lo.y; fa[a][2] = hi.x; fa[a][3] = hi.y;
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = wn * (BN / 2) + b * 16 + r;
+        const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 2 * ((2 * g) ^ swz_d));
+        const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 2 * ((2 * g + 1) ^ swz_d));
+        fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+      __syncthreads();  // (waits for this wave's DMA of the next stage -- vmcnt(0) -- then for every wave)
+    };
+    if (kbeg < kend) {
+      dma_fill(kbeg, 0);
+      __syncthreads();
+      for (int k0 = kbeg; k0 < kend; k0 += 2 * GEMM_BK) {
+        dma_stage(k0, 0);
+        if (k0 + GEMM_BK < kend) dma_stage(k0 + GEMM_BK, 1);
+      }
+    }
+  } else if (kbeg < kend) {
     gload(kbeg);
     sstore(0);
     __syncthreads();
@@ -415,6 +482,14 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
   if (BM * BN <= 64 * 64 && p.beta != 0.0 && p.K <= 128 && nsplit == 1) {
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
   } else {
+    if constexpr (TA == 0 && TB == 1) {
+      // NT form on full tiles (every update of the Cholesky): operands by LDS-DMA
+      static const int dma = getenv("GPRX_GEMM_DMA") ? atoi(getenv("GPRX_GEMM_DMA")) : GPRX_GEMM_DMA_DEFAULT;
+      if (dma && p.M % BM == 0 && p.N % BN == 0 && p.K % GEMM_BK == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0) {
+        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, BM, BN, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+        return hipGetLastError();
+      }
+    }
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, 0>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
   }
   return hipGetLastError();
