@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 
@@ -36,30 +38,40 @@ struct RcclApi {
     std::lock_guard<std::mutex> guard(mu);
     if (lib) return true;
     error.clear();
-    // (1) an RCCL this process has already loaded (e.g. PyTorch's: then the HIP runtime in use is PyTorch's too);
-    // (2) the RCCL that sits NEXT TO the HIP runtime this library is bound to -- one ROCm tree for HIP, HSA and RCCL.
-    //     Measured on the MI355X box: libgprx bound to /opt/rocm's HIP + the RCCL found first on the search path (the
-    //     copy PyTorch ships) fails in ncclCommInitRank ("pfn_hsa_system_get_info failed with 4107"): that RCCL opens its
-    //     own second copy of the HSA runtime, which nobody initialised;
-    // (3) the default search path.
+    const bool dbg = getenv("GPRX_COMM_DEBUG") != nullptr;
+    auto try_open = [&](const std::string& name, int flags, const char* stage) {
+      dlerror();
+      void* h = dlopen(name.c_str(), flags);
+      if (dbg) fprintf(stderr, "[gprx comm] %s dlopen(%s) -> %s%s\n", stage, name.c_str(), h ? "ok" : "failed: ", h ? "" : (dlerror() ? dlerror() : "?"));
+      return h;
+    };
     const char* names[] = {"librccl.so.1", "librccl.so"};
-    for (const char* n : names)
-      if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-    if (!lib) {
+    {
+      // (1) the RCCL that sits NEXT TO the HIP runtime this library calls, by full path and RTLD_LOCAL -- even when another
+      // RCCL is already in the process.  Measured on the MI355X box: every process there has PyTorch's librccl.so (with
+      // PyTorch's own libamdhip64 / libhsa-runtime64) mapped before user code runs; using THAT copy from a library bound to
+      // /opt/rocm's HIP fails in ncclCommInitRank ("pfn_hsa_system_get_info failed with 4107", "no ROCm-capable device"):
+      // its HIP / HSA runtime is a second, uninitialised one.  One ROCm tree for HIP, HSA and RCCL.
+      hipError_t (*volatile fn)(unsigned int) = &hipInit;  // (volatile: the function's own address, not this library's PLT stub)
       Dl_info info;
-      if (dladdr(reinterpret_cast<void*>(&hipInit), &info) && info.dli_fname) {
+      if (dladdr(reinterpret_cast<void*>(fn), &info) && info.dli_fname) {
         std::string dir(info.dli_fname);
+        if (dbg) fprintf(stderr, "[gprx comm] HIP runtime in use: %s\n", dir.c_str());
         const size_t slash = dir.rfind('/');
-        if (slash != std::string::npos) {
+        if (slash != std::string::npos && dir.find("libamdhip64") != std::string::npos) {
           dir.resize(slash + 1);
           for (const char* n : names)
-            if ((lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+            if ((lib = try_open(dir + n, RTLD_NOW | RTLD_LOCAL, "next to HIP:"))) break;
         }
       }
     }
+    // (2) an RCCL the process has already loaded, (3) the search path
+    if (!lib)
+      for (const char* n : names)
+        if ((lib = try_open(n, RTLD_NOW | RTLD_NOLOAD, "already loaded?"))) break;
     if (!lib)
       for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if ((lib = try_open(n, RTLD_NOW | RTLD_LOCAL, "search path:"))) break;
     if (!lib) {
       error = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
       return false;

@@ -49,8 +49,11 @@ struct GemmArgs {
   int alpha_stride = 0;
 };
 
+#ifndef GPRX_GEMM_PFC_DEFAULT
+#define GPRX_GEMM_PFC_DEFAULT 2
+#endif
 #ifndef GPRX_GEMM_DMA_DEFAULT
-#define GPRX_GEMM_DMA_DEFAULT 0
+#define GPRX_GEMM_DMA_DEFAULT 1
 #endif
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_LDK = GEMM_BK;  // KC image row stride (doubles): 128 B, unpadded; the eight 16-B chunks of a row are XOR-swizzled
@@ -133,7 +136,7 @@ __device__ __forceinline__ void glds16(const double* src, double* lds_wave_base)
 }
 
 template <int TA, int TB, int BM, int BN, int PF = 0, int AXF = 0, int DMA = 0>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : ((PF || AXF) ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) || AXF) ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
   static_assert(!DMA || (TA == 0 && TB == 1 && AXF == 0), "the LDS-DMA staging exists for the NT form only");
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
@@ -479,17 +482,24 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
   } else {
     p.nwg = p.tiles_m * p.tiles_n;
   }
+  if constexpr (TA == 0 && TB == 1) {
+    // NT form on full tiles (every update of the Cholesky): both operands by LDS-DMA.  With the operands off the register
+    // file the 64 x 64 kernel has room to fetch its C tile BEFORE the main loop (32 registers: still 4 workgroups per CU),
+    // so the read-modify-write of C costs no exposed latency (GPRX_GEMM_PFC: 1 = for short K only, 2 = at any K).
+    static const int dma = getenv("GPRX_GEMM_DMA") ? atoi(getenv("GPRX_GEMM_DMA")) : GPRX_GEMM_DMA_DEFAULT;
+    static const int pfc = getenv("GPRX_GEMM_PFC") ? atoi(getenv("GPRX_GEMM_PFC")) : GPRX_GEMM_PFC_DEFAULT;
+    if (dma && p.M % BM == 0 && p.N % BN == 0 && p.K % GEMM_BK == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0) {
+      const bool prefetch_c = BM * BN <= 64 * 64 && p.beta != 0.0 && nsplit == 1 && (pfc >= 2 || (pfc == 1 && p.K <= 128));
+      if (prefetch_c)
+        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+      else
+        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, BM, BN, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+      return hipGetLastError();
+    }
+  }
   if (BM * BN <= 64 * 64 && p.beta != 0.0 && p.K <= 128 && nsplit == 1) {
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
   } else {
-    if constexpr (TA == 0 && TB == 1) {
-      // NT form on full tiles (every update of the Cholesky): operands by LDS-DMA
-      static const int dma = getenv("GPRX_GEMM_DMA") ? atoi(getenv("GPRX_GEMM_DMA")) : GPRX_GEMM_DMA_DEFAULT;
-      if (dma && p.M % BM == 0 && p.N % BN == 0 && p.K % GEMM_BK == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0) {
-        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, BM, BN, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
-        return hipGetLastError();
-      }
-    }
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, BM, BN, 0>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
   }
   return hipGetLastError();
@@ -610,6 +620,15 @@ inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A,
   const int nwg = tn * (tn + 1) / 2 + (tm - tn) * tn;
   hipLaunchKernelGGL(syrk_k64_kernel, dim3(nwg, batch), dim3(256), 0, st, A, A, C, lda, ldc, M, N, tn, cs);
   return hipGetLastError();
+}
+inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda, const double* B,
+                              int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile, int batch, int64_t strideA, int64_t strideB,
+                              int64_t strideC, int cells, int64_t cellA, int64_t cellB, int64_t cellC, const double* alpha_tab, int alpha_stride);
+// the K = 64 in-block update: the single-stage kernel above, or (GPRX_K64_GEMM=1, experiments) the general NT kernel
+inline hipError_t launch_update_k64(hipStream_t st, int M, int N, const double* A, int64_t lda, double* C, int64_t ldc, int batch, int64_t cs) {
+  static const int via_gemm = getenv("GPRX_K64_GEMM") ? atoi(getenv("GPRX_K64_GEMM")) : 0;
+  if (!via_gemm) return launch_syrk_k64(st, M, N, A, lda, C, ldc, batch, cs);
+  return launch_gemm(st, 0, 1, M, N, 64, -1.0, A, lda, A, lda, 1.0, C, ldc, GEMM_C_LOWER, 64, batch, cs, cs, cs, 1, 0, 0, 0, nullptr, 0);
 }
 
 // tile: 0 = choose, 128 or 64 (square workgroup tiles)

@@ -1020,7 +1020,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     const double* L21 = A + (int64_t)c1 * lda + c0;
     double* A22 = A + (int64_t)c1 * lda + c1;
     mark_gemm(st, n, rows - n, n, k, k <= 128);  // K <= 128 runs the short-K kernels (syrk_k64 / C-prefetch GEMM), longer K the main GEMM kernel
-    hipError_t e = (k == NB) ? launch_syrk_k64(st, rows, n, L21, lda, A22, lda, batch, cs)
+    hipError_t e = (k == NB) ? launch_update_k64(st, rows, n, L21, lda, A22, lda, batch, cs)
                              : launch_gemm(st, 0, 1, rows, n, k, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64, batch, cs, cs, cs);
     mark_end(st);
     if (e != hipSuccess && err == hipSuccess) err = e;

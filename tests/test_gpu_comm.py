@@ -29,7 +29,11 @@ def device_count(lib):
 def test_world_of_one_every_entry_point(lib):
     from gpras_amd.comm import Communicator
 
-    comm = Communicator.bootstrap(0, rank=0, world=1)
+    try:
+        comm = Communicator.bootstrap(0, rank=0, world=1)
+    except RuntimeError:
+        print("LOADED:", sorted({ln.split()[-1] for ln in open("/proc/self/maps") if any(k in ln for k in ("hsa", "amdhip", "rccl"))}))
+        raise
     try:
         a = np.arange(12, dtype=np.float64).reshape(3, 4) * 1.5
         (got,) = comm.all_gather(a)

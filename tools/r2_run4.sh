@@ -19,9 +19,7 @@ except Exception as e:
 maps = sorted({l.split()[-1] for l in open("/proc/self/maps") if any(k in l for k in ("hsa", "amdhip", "rccl", "libdrm"))})
 print(mode, "loaded:", maps)
 PY
-for mode in plain sk pytestmod; do NCCL_DEBUG=WARN timeout -k 10 120 python /tmp/commdiag.py $mode 2>&1 | grep -v "alt_rsmi\|iommu" | tail -6 | cut -c1-600; done
+for mode in plain; do PYTHONPATH=$GRAFT_REPO_ROOT GPRX_COMM_DEBUG=1 NCCL_DEBUG=WARN timeout -k 10 120 python /tmp/commdiag.py $mode 2>&1 | grep -v "alt_rsmi\|iommu" | tail -6 | cut -c1-600; done
+echo "--- env"; env | grep -i "LD_LIBRARY\|ROCM\|HSA\|HIP" | head
 echo "--- pytest with INFO"
-NCCL_DEBUG=INFO timeout -k 10 200 python -m pytest tests/test_gpu_comm.py -q -s -k world_of_one 2>&1 | grep -v "alt_rsmi\|iommu\|Channel" | grep -i "librccl\|hsa\|warn\|passed\|failed\|ROCr" | head -20 | cut -c1-400
-echo "--- gemm A/B (DMA)"
-cp gpras_amd/libgprx.so tools/libgprx_base.so
-GPRX_GEMM_DMA=1 timeout -k 10 300 python tools/gemm_ab2.py 2>&1 | tail -20
+NCCL_DEBUG=INFO timeout -k 10 200 python -m pytest tests/test_gpu_comm.py -q -s -k world_of_one 2>&1 | grep -v "alt_rsmi\|iommu\|Channel" | grep -i "librccl\|hsa\|warn\|passed\|failed\|ROCr\|LOADED" | head -30 | cut -c1-600
