@@ -50,7 +50,7 @@ struct GemmArgs {
 };
 
 #ifndef GPRX_GEMM_PFC_DEFAULT
-#define GPRX_GEMM_PFC_DEFAULT 2
+#define GPRX_GEMM_PFC_DEFAULT 1
 #endif
 #ifndef GPRX_GEMM_DMA_DEFAULT
 #define GPRX_GEMM_DMA_DEFAULT 1
