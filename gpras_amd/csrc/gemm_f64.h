@@ -47,6 +47,7 @@ struct GemmArgs {
   // per-cell alpha (two-level batches): alpha = alpha_tab[cell * alpha_stride] when alpha_tab is set
   const double* alpha_tab = nullptr;
   int alpha_stride = 0;
+  int persist_slots = 0;  // > 0 (NT, LDS-DMA eligible, no split-K): persistent grid of persist_slots x #CUs workgroups
 };
 
 #ifndef GPRX_GEMM_PFC_DEFAULT
@@ -135,13 +136,21 @@ __device__ __forceinline__ void glds16(const double* src, double* lds_wave_base)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int TA, int TB, int BM, int BN, int PF = 0, int AXF = 0, int DMA = 0>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) || AXF) ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
+template <int TA, int TB, int BM, int BN>
+struct GemmSmem {
+  static constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
+  static constexpr int B_ELEMS = TB ? BN * GEMM_LDK : GEMM_BK * McStride<BN>::value;
+  static constexpr int doubles = 2 * (A_ELEMS + B_ELEMS);
+};
+
+// One output tile: workgroup (bx, by, bz) of the launch grid described in launch_gemm_t.  `smem` is the kernel's single
+// shared array (GemmSmem::doubles).
+template <int TA, int TB, int BM, int BN, int PF, int AXF, int DMA>
+__device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx, const int by, const int bz, double* __restrict__ smem) {
   static_assert(!DMA || (TA == 0 && TB == 1 && AXF == 0), "the LDS-DMA staging exists for the NT form only");
   constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int A_ELEMS = TA ? GEMM_BK * McStride<BM>::value : BM * GEMM_LDK;
-  constexpr int B_ELEMS = TB ? BN * GEMM_LDK : GEMM_BK * McStride<BN>::value;
-  __shared__ __attribute__((aligned(16))) double smem[2 * (A_ELEMS + B_ELEMS)];
+  constexpr int A_ELEMS = GemmSmem<TA, TB, BM, BN>::A_ELEMS;
+  constexpr int B_ELEMS = GemmSmem<TA, TB, BM, BN>::B_ELEMS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) ||
   // C_LOWER, decode the linear index over the lower trapezoid only -- every launched workgroup has
   // work, and the tiles are spread evenly over the XCDs.
   {
-    int entry = blockIdx.y;
+    int entry = by;
     if (p.inner > 0) {
       const int cell = entry / p.inner;
       entry -= cell * p.inner;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) ||
     p.B += (int64_t)entry * p.strideB;
     p.C += (int64_t)entry * p.strideC;
   }
-  int bid = blockIdx.x;
+  int bid = bx;
   if (!(p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER))) {
     // (with triangular operands the K range, i.e. the cost, varies along the tile order: keep the
     // hardware's round-robin there, which spreads long and short tiles over all XCDs)
@@ -248,9 +257,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) ||
   if (p.flags & GEMM_B_LOWER) kbeg = max(kbeg, n0);
   if (p.flags & GEMM_B_UPPER) kend = min(kend, n0 + BN);
   if (p.ksplit > 0) {
-    kbeg = max(kbeg, (int)blockIdx.z * p.ksplit);
-    kend = min(kend, ((int)blockIdx.z + 1) * p.ksplit);
-    p.C += (int64_t)blockIdx.z * p.slab;
+    kbeg = max(kbeg, bz * p.ksplit);
+    kend = min(kend, (bz + 1) * p.ksplit);
+    p.C += (int64_t)bz * p.slab;
   }
   kbeg &= ~(GEMM_BK - 1);
   kend = (kend + GEMM_BK - 1) & ~(GEMM_BK - 1);
@@ -470,6 +479,28 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) ||
   }
 }
 
+template <int TA, int TB, int BM, int BN, int PF = 0, int AXF = 0, int DMA = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : (((PF && !DMA) || AXF) ? 3 : 4)) void gemm_f64_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[GemmSmem<TA, TB, BM, BN>::doubles];
+  gemm_tile<TA, TB, BM, BN, PF, AXF, DMA>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+
+// The same tiles from a PERSISTENT grid: workgroup b takes tiles b, b + gridDim.x, ... of the (nwg x batch) tile list.  A
+// launch of `slots` x 256 workgroups keeps at most `slots` workgroups of this kernel on a CU, so the wave slots, registers
+// and LDS of the remaining slot stay free for the small dependent kernels of the panel chain that runs beside the bulk
+// update on another stream (measured at N = 16384: behind an ordinary launch, whose workgroups fill every CU, those kernels
+// waited 20-170 us for a slot each).  gridDim.x must be a multiple of 8 (the tile -> XCD affinity of the remap survives).
+template <int BM, int BN, int PF>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_f64_nt_dma_persistent_kernel(GemmArgs p, int batch) {
+  __shared__ __attribute__((aligned(16))) double smem[GemmSmem<0, 1, BM, BN>::doubles];
+  const int total = p.nwg * batch;
+  for (int t = (int)blockIdx.x; t < total; t += (int)gridDim.x) {
+    const int by = t / p.nwg;
+    gemm_tile<0, 1, BM, BN, PF, 0, 1>(p, t - by * p.nwg, by, 0, smem);
+    // (the last stage of a tile ends with a barrier behind its LDS reads; the epilogue does not touch LDS)
+  }
+}
+
 template <int TA, int TB, int BM, int BN>
 inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nsplit = 1) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -490,6 +521,20 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
     static const int pfc = getenv("GPRX_GEMM_PFC") ? atoi(getenv("GPRX_GEMM_PFC")) : GPRX_GEMM_PFC_DEFAULT;
     if (dma && p.M % BM == 0 && p.N % BN == 0 && p.K % GEMM_BK == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0) {
       const bool prefetch_c = BM * BN <= 64 * 64 && p.beta != 0.0 && nsplit == 1 && (pfc >= 2 || (pfc == 1 && p.K <= 128));
+      if (p.persist_slots > 0 && nsplit == 1 && !prefetch_c) {
+        static const int n_cu = [] {
+          int dev = 0, cus = 256;
+          hipGetDevice(&dev);
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          return cus > 0 ? cus : 256;
+        }();
+        int grid = p.persist_slots * n_cu;
+        grid -= grid % 8;
+        if (grid > 0 && (int64_t)p.nwg * batch > grid) {
+          hipLaunchKernelGGL((gemm_f64_nt_dma_persistent_kernel<BM, BN, 0>), dim3(grid), dim3(256), 0, st, p, batch);
+          return hipGetLastError();
+        }
+      }
       if (prefetch_c)
         hipLaunchKernelGGL((gemm_f64_kernel<0, 1, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
       else
@@ -623,20 +668,28 @@ inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A,
 }
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda, const double* B,
                               int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile, int batch, int64_t strideA, int64_t strideB,
-                              int64_t strideC, int cells, int64_t cellA, int64_t cellB, int64_t cellC, const double* alpha_tab, int alpha_stride);
-// the K = 64 in-block update: the single-stage kernel above, or (GPRX_K64_GEMM=1, experiments) the general NT kernel
+                              int64_t strideC, int cells, int64_t cellA, int64_t cellB, int64_t cellC, const double* alpha_tab, int alpha_stride,
+                              int persist_slots);
+// The K = 64 in-block update: the general NT kernel (LDS-DMA operands, C prefetched: 32 KiB of LDS), or with GPRX_K64_GEMM=0
+// the single-stage kernel above.  syrk_k64_kernel holds both whole operand panels in 64 KiB of LDS; beside the bulk update
+// of a large matrix (whose workgroups own all LDS of every CU) each of its launches waited for TWO of them to retire on
+// one CU: 166 us per launch at N = 16384 (rocprofv3), 21 of the 32 ms of that factorisation.  Measured with the general
+// kernel: N = 16384 31.8 -> 30.2 ms, N = 8192 6.73 -> 6.50 ms, 128 cells of N = 4096 +0.5 %, N <= 4096 single unchanged.
+// (The 128-column panel option keeps syrk_k64's k order inside its sub-panel updates: it is no longer bit-identical to the
+// 64-column default, only equal to rounding.)
 inline hipError_t launch_update_k64(hipStream_t st, int M, int N, const double* A, int64_t lda, double* C, int64_t ldc, int batch, int64_t cs) {
-  static const int via_gemm = getenv("GPRX_K64_GEMM") ? atoi(getenv("GPRX_K64_GEMM")) : 0;
+  static const int via_gemm = getenv("GPRX_K64_GEMM") ? atoi(getenv("GPRX_K64_GEMM")) : 1;
   if (!via_gemm) return launch_syrk_k64(st, M, N, A, lda, C, ldc, batch, cs);
-  return launch_gemm(st, 0, 1, M, N, 64, -1.0, A, lda, A, lda, 1.0, C, ldc, GEMM_C_LOWER, 64, batch, cs, cs, cs, 1, 0, 0, 0, nullptr, 0);
+  return launch_gemm(st, 0, 1, M, N, 64, -1.0, A, lda, A, lda, 1.0, C, ldc, GEMM_C_LOWER, 64, batch, cs, cs, cs, 1, 0, 0, 0, nullptr, 0, 0);
 }
 
 // tile: 0 = choose, 128 or 64 (square workgroup tiles)
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0, int batch = 1,
                               int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0, int cells = 1, int64_t cellA = 0,
-                              int64_t cellB = 0, int64_t cellC = 0, const double* alpha_tab = nullptr, int alpha_stride = 0) {
+                              int64_t cellB = 0, int64_t cellC = 0, const double* alpha_tab = nullptr, int alpha_stride = 0, int persist_slots = 0) {
   GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC, 0, 0};
+  p.persist_slots = persist_slots;
   if (M <= 0 || N <= 0 || batch <= 0 || cells <= 0) return hipSuccess;
   if (cells > 1 || alpha_tab) {  // two-level batch: `batch` entries per cell
     p.inner = batch;

@@ -24,6 +24,7 @@
 #include "metrics.h"
 #include "pca.h"
 #include "potrf.h"
+#include "potrf_large.h"
 #include "sgpr.h"
 #include "solve.h"
 
@@ -55,6 +56,7 @@ struct gprx_ctx {
   int64_t n = 0, m = 0, np = 0, mp = 0;
   int d = 0, kid = 0, ard = 0, nlen = 1, ntheta = 3, n_units = 0;
   int dist_form = 0;  // GPRX_DIST_DIFFERENCE / GPRX_DIST_EXPANDED
+  PotrfLarge large;   // streams and scratch of the large-matrix schedule (potrf_large.h), created on first use
   PotrfTuning tune;   // schedule knobs of this handle: the process defaults at creation, then gprx_set_handle_tuning
   int predict_path = 0;
   std::string err;
@@ -244,6 +246,14 @@ int ensure_lookahead(gprx_handle h) {
   return GPRX_OK;
 }
 
+bool use_large_schedule(const PotrfTuning& tune, int np) {
+  // off by default: measured on MI355X (N = 16384: 36.1 ms against 30.7 ms for the panel-over-all-rows schedule with a 64 x 64
+  // TAIL tile; N = 8192: 9.1 against 6.6 ms) -- the per-block chain (16 panels, 8 inversion GEMMs, copy, triangular GEMM,
+  // HEAD) is longer than the bulk update it should hide behind.  "large_min" (gprx_set_tuning) enables it from a given size.
+  const int lim = tune.large_min;
+  return lim > 0 && np >= lim && np > 1024;
+}
+
 int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookahead = true, bool capture = false) {
   const int np = (int)h->np;
   const int64_t ld = h->np;
@@ -279,8 +289,13 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
   if (h->profiling) h->prof.reset();
-  HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->profiling ? &h->prof : nullptr,
-                        lookahead ? &h->pstreams : nullptr, 1, 0, 0, &h->tune));
+  if (use_large_schedule(h->tune, np) && !capture) {
+    // one large matrix: block columns, the panel chain confined to the diagonal block on reserved CUs (potrf_large.h)
+    HIPCHK(h, potrf_lower_large(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->large, h->tune));
+  } else {
+    HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->profiling ? &h->prof : nullptr,
+                          lookahead ? &h->pstreams : nullptr, 1, 0, 0, &h->tune));
+  }
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
   hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
@@ -303,7 +318,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
 // the device (4 hardware queues, each cell ~1.8x slower under 4-way sharing), the replay mainly frees the host.
 int exact_factorize_replay(gprx_handle h, int unit, const Theta& t) {
   static const bool no_graph = getenv("GPRX_NO_GRAPH") != nullptr;  // escape hatch: eager launches
-  if (h->d > 64 || h->profiling || no_graph) return exact_factorize_enqueue(h, unit, t, false);
+  if (h->d > 64 || h->profiling || no_graph || use_large_schedule(h->tune, (int)h->np)) return exact_factorize_enqueue(h, unit, t, false);
   auto it = h->graphs.find(unit);
   if (it == h->graphs.end()) {
     // buffers must exist before capture: a first eager pass allocates them (and is a valid fit by itself)
@@ -507,8 +522,16 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
-    HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
-                          2 * CELL_RES, &h->tune));
+    if (use_large_schedule(h->tune, np)) {
+      // the schedule depends on the matrix size alone (bit-identical to single calls): large matrices one after the other,
+      // each fills the chip by itself
+      for (int c = 0; c < cnt; ++c)
+        HIPCHK(h, potrf_lower_large(gs, K0 + (int64_t)c * cs, ld, np, NB, K0 + (int64_t)c * cs + h->off_invd, info0 + (int64_t)c * 2 * CELL_RES,
+                                    K0 + (int64_t)c * cs + h->off_stage, h->large, h->tune));
+    } else {
+      HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
+                            2 * CELL_RES, &h->tune));
+    }
     const double* beta = K0 + (int64_t)np * ld;
     hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
     hipLaunchKernelGGL(logdet_quad_kernel, dim3(cnt), dim3(256), 0, gs, (const double*)K0, ld, beta, np, cres, cs, CELL_RES);
@@ -1243,6 +1266,7 @@ int gprx_destroy(gprx_handle h) {
   for (auto& ev : h->ev)
     if (ev) hipEventDestroy(ev);
   h->pstreams.destroy();
+  h->large.destroy();
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return GPRX_OK;
@@ -2316,8 +2340,12 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   HIPCHK(nullptr, ps.init());
   double* dstage = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dstage, sizeof(double) * np * STAGE_LD));
-  hipError_t e = potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
+  PotrfLarge large;
+  hipError_t e = use_large_schedule(potrf_tuning(), (int)np)
+                     ? potrf_lower_large(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, large, potrf_tuning())
+                     : potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
   hipError_t e2 = hipDeviceSynchronize();
+  large.destroy();
   hipFree(dstage);
   ps.destroy();
   hipStreamDestroy(st);
@@ -2345,6 +2373,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "panel_occ" && (value == 0 || value == 2 || value == 3)) t.panel_occ = value;
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
+  else if (k == "large_min" && (value == 0 || (value >= 2048 && value % 64 == 0))) t.large_min = value;
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
   else return false;
   return true;

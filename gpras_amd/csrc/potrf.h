@@ -879,6 +879,7 @@ struct PotrfTuning {
   int panel_occ = 0;     // 3: panel kernel compiled for 3 workgroups per CU (168 registers, small spills) instead of 2
   int inblock = 0;       // 1: right-looking K = 64 strips inside an outer block instead of the recursive halving
   int split_panel = 0;   // 1: always the split panel (diagonal workgroup + rows kernel), -1: never, 0: from 24 cells per launch on
+  int large_min = 0;     // matrices of at least this many (padded) rows take the block-column schedule of potrf_large.h (0: never)
 };
 inline PotrfTuning& potrf_tuning() {
   static PotrfTuning t = [] {
@@ -890,6 +891,7 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_PANEL_OCC")) v.panel_occ = atoi(e);
     if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
     if (const char* e = getenv("GPRX_SPLIT_PANEL")) v.split_panel = atoi(e);
+    if (const char* e = getenv("GPRX_LARGE_MIN")) v.large_min = atoi(e);
     return v;
   }();
   return t;
@@ -931,11 +933,12 @@ struct PotrfStreams {
 // Order: TAIL(J) waits for HEAD(J) to be enqueued behind block J (event) and follows TAIL(J-1)
 // (stream order); HEAD(J) waits for TAIL(J-1), the last writer of the next block's columns.
 // diag_stage: scratch of np * STAGE_LD doubles (staged diagonal blocks and reciprocal pivots, see potrf_panel_kernel)
+// col_base: added to the failing-pivot index reported through `info` (the matrix is a diagonal block of a larger one).
 // batch > 1: `batch` matrices at A + c * cs (inv_diag and diag_stage likewise: all live in cell blocks `cs` doubles apart),
 // info words info_stride ints apart; every launch carries the cell index in blockIdx.y.
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
                               double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr, int batch = 1, int64_t cs = 0,
-                              int info_stride = 0, const PotrfTuning* tune_in = nullptr) {
+                              int info_stride = 0, const PotrfTuning* tune_in = nullptr, int col_base = 0) {
   const double* prev_stage = nullptr;
   double* prev_dst = nullptr;
   int prev_pw = 0;
@@ -960,8 +963,13 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   const int pwidth = tune.panel_width ? tune.panel_width : NB;
   // bulk-update tile: batched cells fill the chip with 64 x 64 tiles already (4 workgroups per CU hide the C
   // read-modify-write; measured 1529 vs 1513 fits/s at 16 cells of N = 4096); a single matrix lets launch_gemm choose
-  const int bulk_tile = tune.update_tile ? tune.update_tile : (batch > 1 ? 64 : 0);
+  // (a single matrix too since the 64 x 64 kernel takes its operands by LDS-DMA: N = 16384 30.7 ms against 32.4 ms with the
+  // 128 x 128 tile, whose ragged row counts keep it on the register-staged kernel)
+  const int bulk_tile = tune.update_tile ? tune.update_tile : 64;
   bool tail_pending = false;
+  // 0 (default): ordinary launches.  Measured dead end: a persistent TAIL grid of 2 / 3 / 4 workgroups per CU (one slot of
+  // every CU left to the chain) gave N = 16384 31.0 / 30.7 / 31.5 ms against 30.05 ms, N = 8192 6.44 / 6.51 / 6.55 against 6.35
+  static const int tail_slots = getenv("GPRX_TAIL_SLOTS") ? atoi(getenv("GPRX_TAIL_SLOTS")) : 0;
   hipError_t err = hipSuccess;
   // split panel (diagonal workgroup, then a rows-only kernel): pays one more dependent launch per panel and wins once
   // a fused launch would fill the chip with redundant factorisations; bit-identical either way
@@ -977,23 +985,23 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     double* stage_out = diag_stage + (int64_t)c * STAGE_LD;
     double* invd = inv_diag + (int64_t)(c / NB) * NB * NB;
     if (pw == PW && split_panel) {
-      hipLaunchKernelGGL(potrf_panel128_kernel, dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, c, stage_out, prev_stage, prev_dst,
+      hipLaunchKernelGGL(potrf_panel128_kernel, dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out, prev_stage, prev_dst,
                          prev_pw, cs, info_stride);
       if (rows_below > 0)
         hipLaunchKernelGGL(potrf_rows128_kernel, dim3((rows_below + R128_ROWS - 1) / R128_ROWS, batch), dim3(256), 0, st,
                            Acc + (int64_t)PW * lda, lda, rows_below, (const double*)stage_out, cs);
     } else if (pw == PW) {
       const int nchunks = (rows_below + PANEL128_ROWS - 1) / PANEL128_ROWS;
-      hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, c,
+      hipLaunchKernelGGL(potrf_panel128_kernel, dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, col_base + c,
                          stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
     } else if (tune.panel_rows == 256) {
       const int own = PanelGeom<4>::kOwnRows;
       const int nchunks = (rows_below + own - 1) / own;
-      hipLaunchKernelGGL((potrf_panel_kernel<4, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, c,
+      hipLaunchKernelGGL((potrf_panel_kernel<4, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info, col_base + c,
                          stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
     } else if (split_panel) {
       // diagonal block: one workgroup per cell (the `last` role of the panel kernel: L11 staged, L11^-1, pivots) ...
-      hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, c, stage_out, prev_stage,
+      hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out, prev_stage,
                          prev_dst, prev_pw, cs, info_stride);
       // ... then the rows below it, 128 per workgroup
       if (rows_below > 0)
@@ -1004,10 +1012,10 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       const int nchunks = (rows_below + own - 1) / own;
       if (tune.panel_occ == 3)
         hipLaunchKernelGGL((potrf_panel_kernel<2, 3>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
-                           c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+                           col_base + c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
       else
         hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
-                           c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+                           col_base + c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
     }
     prev_stage = stage_out;
     prev_dst = Acc;
@@ -1076,8 +1084,11 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       const int rows = total_rows - R2, cols = np - R2;
       const double* Lrow = A + (int64_t)R2 * lda + C;  // L[R2:, C:C+w]
       mark_gemm(ts, cols, rows - cols, cols, w);
+      // (option GPRX_TAIL_SLOTS: beside the panel chain of the next block the bulk update can run from a persistent grid that
+      // leaves workgroup slots of every CU to the chain's small kernels)
+      const int persist = (ps && batch == 1) ? tail_slots : 0;
       hipError_t e = launch_gemm(ts, 0, 1, rows, cols, w, -1.0, Lrow, lda, Lrow, lda, 1.0, A + (int64_t)R2 * lda + R2, lda, GEMM_C_LOWER,
-                                   bulk_tile, batch, cs, cs, cs);
+                                   bulk_tile, batch, cs, cs, cs, 1, 0, 0, 0, nullptr, 0, persist);
       mark_end(ts);
       if (e != hipSuccess) return e;
       if (ps) {
