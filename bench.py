@@ -271,8 +271,9 @@ def main():
             extra["predict_n_test"] = N_TEST
             # BASELINE configs[3] per GPU: independent cells, each fitted (batched) and predicted at the shared 100k test points
             # (gprx_predict_batch: host buffers in and out, i.e. PCIe-inclusive)
-            c4 = 4
+            c4 = 8
             pm, pv = np.zeros((c4, N_TEST)), np.zeros((c4, N_TEST))
+            check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), 1000, ptr(pm), ptr(pv), 1), h)  # (allocations)
             t1 = time.perf_counter()
             check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), N_TEST, ptr(pm), ptr(pv), 1), h)
             tc4 = time.perf_counter() - t1

@@ -48,6 +48,11 @@ struct GemmArgs {
   const double* alpha_tab = nullptr;
   int alpha_stride = 0;
   int persist_slots = 0;  // > 0 (NT, LDS-DMA eligible, no split-K): persistent grid of persist_slots x #CUs workgroups
+  // rowsq != nullptr: C is NOT stored; instead rowsq[(2 tj + wn) * rowsq_ld + row] = sum over the 16 TN columns of this wave
+  // of (alpha * acc)^2 -- the row sums of squares of the product in 2 * tiles_n partial slabs (summed by rowsq_final_kernel
+  // in a fixed order).  The predictive variance needs only these sums of V^T = Ks^T L^-T, never V itself.
+  double* rowsq = nullptr;
+  int64_t rowsq_ld = 0;
 };
 
 #ifndef GPRX_GEMM_PFC_DEFAULT
@@ -444,6 +449,28 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx, const int by
   // epilogue: lane holds rows g + 4q (q = 0..3) of column r of each 16 x 16 tile.  The C reads of a
   // tile row are all issued before the first store (a load -> store -> load chain is latency-bound).
   const double alpha = p.alpha, beta = p.beta;
+  if (p.rowsq) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double ssq = 0.0;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = n0 + wn * (BN / 2) + b * 16 + r;
+          const double v = col < p.N ? alpha * acc[a][b][q] : 0.0;
+          ssq = __builtin_fma(v, v, ssq);
+        }
+        // the 16 lanes that share g hold the 16 columns r = 0..15 of this row
+        ssq += __shfl_xor(ssq, 1, 64);
+        ssq += __shfl_xor(ssq, 2, 64);
+        ssq += __shfl_xor(ssq, 4, 64);
+        ssq += __shfl_xor(ssq, 8, 64);
+        const int row = m0 + wm * (BM / 2) + a * 16 + g + 4 * q;
+        if (r == 0 && row < p.M) p.rowsq[(int64_t)(2 * tj + wn) * p.rowsq_ld + row] = ssq;
+      }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     double cold[TN][4];
@@ -669,7 +696,7 @@ inline hipError_t launch_syrk_k64(hipStream_t st, int M, int N, const double* A,
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda, const double* B,
                               int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile, int batch, int64_t strideA, int64_t strideB,
                               int64_t strideC, int cells, int64_t cellA, int64_t cellB, int64_t cellC, const double* alpha_tab, int alpha_stride,
-                              int persist_slots);
+                              int persist_slots, double* rowsq, int64_t rowsq_ld);
 // The K = 64 in-block update: the general NT kernel (LDS-DMA operands, C prefetched: 32 KiB of LDS), or with GPRX_K64_GEMM=0
 // the single-stage kernel above.  syrk_k64_kernel holds both whole operand panels in 64 KiB of LDS; beside the bulk update
 // of a large matrix (whose workgroups own all LDS of every CU) each of its launches waited for TWO of them to retire on
@@ -680,16 +707,19 @@ inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int 
 inline hipError_t launch_update_k64(hipStream_t st, int M, int N, const double* A, int64_t lda, double* C, int64_t ldc, int batch, int64_t cs) {
   static const int via_gemm = getenv("GPRX_K64_GEMM") ? atoi(getenv("GPRX_K64_GEMM")) : 1;
   if (!via_gemm) return launch_syrk_k64(st, M, N, A, lda, C, ldc, batch, cs);
-  return launch_gemm(st, 0, 1, M, N, 64, -1.0, A, lda, A, lda, 1.0, C, ldc, GEMM_C_LOWER, 64, batch, cs, cs, cs, 1, 0, 0, 0, nullptr, 0, 0);
+  return launch_gemm(st, 0, 1, M, N, 64, -1.0, A, lda, A, lda, 1.0, C, ldc, GEMM_C_LOWER, 64, batch, cs, cs, cs, 1, 0, 0, 0, nullptr, 0, 0, nullptr, 0);
 }
 
 // tile: 0 = choose, 128 or 64 (square workgroup tiles)
 inline hipError_t launch_gemm(hipStream_t st, int ta, int tb, int M, int N, int K, double alpha, const double* A, int64_t lda,
                               const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int tile = 0, int batch = 1,
                               int64_t strideA = 0, int64_t strideB = 0, int64_t strideC = 0, int cells = 1, int64_t cellA = 0,
-                              int64_t cellB = 0, int64_t cellC = 0, const double* alpha_tab = nullptr, int alpha_stride = 0, int persist_slots = 0) {
+                              int64_t cellB = 0, int64_t cellC = 0, const double* alpha_tab = nullptr, int alpha_stride = 0, int persist_slots = 0,
+                              double* rowsq = nullptr, int64_t rowsq_ld = 0) {
   GemmArgs p{A, B, C, lda, ldb, ldc, M, N, K, alpha, beta, flags, 0, 0, 0, strideA, strideB, strideC, 0, 0};
   p.persist_slots = persist_slots;
+  p.rowsq = rowsq;
+  p.rowsq_ld = rowsq_ld;
   if (M <= 0 || N <= 0 || batch <= 0 || cells <= 0) return hipSuccess;
   if (cells > 1 || alpha_tab) {  // two-level batch: `batch` entries per cell
     p.inner = batch;

@@ -637,7 +637,10 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   // (measured at 32 cells of N = 4096: 52.8 ms against 60.7 ms per batched objective + gradient)
   const int tile = h->tune.update_tile ? h->tune.update_tile : 64;
   HIPCHK(h, trtri_lower(st, K0, ld, K0 + h->off_invd, X0, ld, T0, ld, np, count, cs, gs, tile));
-  HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, tile, count, gs, gs,
+  // K^-1 = L^-T L^-1 on the lower tiles, as an NT product of Xt = L^-T with itself (transposed in place; same sums in the same
+  // k order as the TN form it replaces, so the values are unchanged)
+  HIPCHK(h, transpose_inplace(st, X0, ld, np, count, gs));
+  HIPCHK(h, launch_gemm(st, 0, 1, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, tile, count, gs, gs,
                         gs));
   TraceArgs ta{h->X.p, h->X.p, nullptr, T0, ld, K0 + h->off_alpha, K0 + h->off_alpha, -1.0, 1.0, (int)h->n, (int)h->n, h->d, 0.0, 1, h->gpartial.p,
                nullptr, 0, tiles};
@@ -678,9 +681,10 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   hipStream_t st = h->stream;
   HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0, sizeof(double) * h->np * ld, st));
   HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
-  h->have_linv = true;
-  // K^-1 = X^T X, lower tiles, into Tmp
-  HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld,
+  // K^-1 = X^T X on the lower tiles, into Tmp: NT product of Xt = L^-T (X transposed in place) with itself
+  HIPCHK(h, transpose_inplace(st, h->Xinv.p, ld, np));
+  h->have_linv = false;  // Xinv now holds L^-T: a later predict forms L^-1 again
+  HIPCHK(h, launch_gemm(st, 0, 1, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld,
                         GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, h->tune.update_tile));
   const int tiles = np / KM_T;
   const int width = 2 + h->d;
@@ -1561,6 +1565,50 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
 
 static constexpr int PRED_TILE = 8192;
 
+// what one exact factorisation contributes to a prediction through the explicit inverse: alpha, L^-1, the kernel's
+// hyperparameters (a device lengthscale vector, or a row of the cell-parameter table) and the variance offset
+struct ExactPredictSrc {
+  const double* alpha;
+  const double* Xinv;
+  const double* ls_dev;
+  const double* cell_par;  // row of the batch's cell-parameter table ([0] variance, [8..] lengthscales) or nullptr
+  double variance, base;   // base = variance (+ noise for predict_y)
+};
+
+// transposed formulation, test points along the rows: Kst = k(Xs, X) (ts x np), mean = Kst alpha (row dots),
+// Vt = Kst L^-T as an NT GEMM -- both operands k-contiguous, the GEMM kernel's fastest case; op(B) = L^-T is
+// upper triangular, so the K range of a tile ends at its last column and every tile row mixes short and long
+// tiles (no tail of long tiles) -- and var = base - row sums of Vt^2.  h->Ks holds 2 x np x tile doubles.
+static int exact_predict_inverse(gprx_handle h, const ExactPredictSrc& src, const double* xs_dev, int64_t ns, double* mean_dev, double* var_dev,
+                                 int tile) {
+  const int np = (int)h->np;
+  const int64_t ld = h->np;
+  hipStream_t st = h->stream;
+  double* Vbuf = h->Ks.p + (size_t)h->np * tile;
+  for (int64_t t0 = 0; t0 < ns; t0 += tile) {
+    const int ts = (int)std::min<int64_t>(tile, ns - t0);
+    const int tsp = (int)round_up(ts, NB);
+    KmatArgs ka{xs_dev + t0 * h->d, h->X.p, src.ls_dev, h->Ks.p, ld, ts, (int)h->n, h->d, tsp, np, src.variance, 0.0, 0, 0.0, nullptr, 0};
+    if (src.cell_par) {  // hyperparameters of a batch slot: straight from the device table (no upload, no synchronisation)
+      ka.cell_par = src.cell_par;
+      ka.diag_const = 1;
+    }
+    HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
+    hipLaunchKernelGGL(rowreduce_kernel, dim3((ts + 3) / 4), dim3(256), 0, st, (const double*)h->Ks.p, ld, src.alpha, ts, np, 0.0, 1.0, mean_dev + t0);
+    // Vt is never stored: the GEMM's epilogue leaves the row sums of squares of its tiles (2 slabs per tile column), which
+    // the final kernel adds in a fixed order -- 2 x 8 np tile bytes less HBM traffic per tile than storing and re-reading Vt
+    // 64 x 64 tiles: operands by LDS-DMA and finer clipping of the triangular K range (measured at N = 4096, 100 000 points:
+    // 3.65 M points/s = 61.2 TFLOP/s against 3.35 M with the 128 x 128 register-staged kernel)
+    static const int ptile = getenv("GPRX_PREDICT_TILE") ? atoi(getenv("GPRX_PREDICT_TILE")) : 64;
+    const int nparts = 2 * ((np + ptile - 1) / ptile);
+    HIPCHK(h, launch_gemm(st, 0, 1, tsp, np, np, 1.0, h->Ks.p, ld, src.Xinv, ld, 0.0, Vbuf, ld, GEMM_B_UPPER, ptile, 1, 0, 0, 0, 1, 0, 0, 0, nullptr, 0, 0,
+                          Vbuf, (int64_t)tile));
+    hipLaunchKernelGGL(rowsq_final_kernel, dim3((ts + 255) / 256), dim3(256), 0, st, (const double*)Vbuf, nparts, (int64_t)tile, ts, src.base, var_dev + t0);
+  }
+  HIPCHK(h, hipGetLastError());
+  return GPRX_OK;
+}
+
 int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* mean_dev, double* var_dev, int include_noise) {
   int rc;
   if ((rc = check_handle(h))) return rc;
@@ -1620,23 +1668,8 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   }
   const double base = h->variance + (include_noise ? h->noise : 0.0);
   if (use_inverse) {
-    // transposed formulation, test points along the rows: Kst = k(Xs, X) (ts x np), mean = Kst alpha (row dots),
-    // Vt = Kst L^-T as an NT GEMM -- both operands k-contiguous, the GEMM kernel's fastest case; op(B) = L^-T is
-    // upper triangular, so the K range of a tile ends at its last column and every tile row mixes short and long
-    // tiles (no tail of long tiles) -- and var = base - row sums of Vt^2.
-    for (int64_t t0 = 0; t0 < ns; t0 += tile) {
-      const int ts = (int)std::min<int64_t>(tile, ns - t0);
-      const int tsp = (int)round_up(ts, NB);
-      KmatArgs ka{xs_dev + t0 * h->d, h->X.p, h->invls.p, h->Ks.p, ld, ts, (int)h->n, h->d, tsp, np, h->variance, 0.0, 0, 0.0, nullptr, 0};
-      HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
-      hipLaunchKernelGGL(rowreduce_kernel, dim3((ts + 3) / 4), dim3(256), 0, st, (const double*)h->Ks.p, ld, (const double*)h->alpha.p, ts, np, 0.0,
-                         1.0, mean_dev + t0);
-      HIPCHK(h, launch_gemm(st, 0, 1, tsp, np, np, 1.0, h->Ks.p, ld, h->Xinv.p, ld, 0.0, Vbuf, ld, GEMM_B_UPPER, 128));
-      hipLaunchKernelGGL(rowreduce_kernel, dim3((ts + 3) / 4), dim3(256), 0, st, (const double*)Vbuf, ld, (const double*)nullptr, ts, np, base, -1.0,
-                         var_dev + t0);
-    }
-    HIPCHK(h, hipGetLastError());
-    return GPRX_OK;
+    const ExactPredictSrc src{h->alpha.p, h->Xinv.p, h->invls.p, nullptr, h->variance, base};
+    return exact_predict_inverse(h, src, xs_dev, ns, mean_dev, var_dev, tile);
   }
   const int nchunks = (np + rows_per_chunk - 1) / rows_per_chunk;
   if ((rc = ensure(h, h->pred, sizeof(double) * (size_t)nchunks * tile))) return rc;
@@ -1683,10 +1716,43 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
   if (h->m == 0 && h->d <= CELL_PAR - CELL_PAR_LS) {
     // exact models: all factorisations by one batched launch sequence, then every slot predicts
     if ((rc = gprx_factorize_batch(h, count, units, thetas, 0, nullptr, nullptr))) return rc;
-    for (int i = 0; i < count; ++i) {
-      if ((rc = select_slot(h, i))) return rc;
-      if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
+    if (ns == 0) return GPRX_OK;
+    const bool use_inverse = h->predict_path != 2 && (h->n <= 4096 || 2 * ns >= (int64_t)h->n);
+    if (!use_inverse) {
+      for (int i = 0; i < count; ++i) {
+        if ((rc = select_slot(h, i))) return rc;
+        if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
+      }
+      return GPRX_OK;
     }
+    // the test points go up ONCE; L^-1 of every slot by batched launches (trtri_lower with the cell index in its grids);
+    // each slot then predicts with its alpha / L^-1 / row of the parameter table -- no per-cell upload or synchronisation
+    const int np = (int)h->np;
+    const int64_t ld = h->np, cs = h->cell_stride, gs = 2 * (int64_t)h->np * h->np;
+    const int tile = (int)std::min<int64_t>(PRED_TILE, round_up(ns, NB));
+    hipStream_t st = h->stream;
+    if ((rc = ensure(h, h->garena, sizeof(double) * (size_t)gs * count))) return rc;
+    if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile * 2))) return rc;
+    if ((rc = ensure(h, h->xs, sizeof(double) * (ns * h->d + 4 * ns)))) return rc;
+    double* dxs = h->xs.p;
+    double* dout = dxs + ns * h->d;  // two (mean, var) staging pairs, used alternately (everything is ordered on the one stream)
+    HIPCHK(h, hipMemcpyAsync(dxs, xs, sizeof(double) * ns * h->d, hipMemcpyHostToDevice, st));
+    for (int c = 0; c < count; ++c) HIPCHK(h, hipMemsetAsync(h->garena.p + (int64_t)c * gs, 0, sizeof(double) * h->np * ld, st));
+    HIPCHK(h, trtri_lower(st, h->arena.p, ld, h->arena.p + h->off_invd, h->garena.p, ld, h->garena.p + (int64_t)np * ld, ld, np, count, cs, gs,
+                          h->tune.update_tile ? h->tune.update_tile : 64));
+    for (int i = 0; i < count; ++i) {
+      const Theta& t = h->slot_theta[i];
+      const double* cpar = h->cellpar.p + (int64_t)i * CELL_PAR;
+      const ExactPredictSrc src{h->arena.p + (int64_t)i * cs + h->off_alpha, h->garena.p + (int64_t)i * gs, nullptr, cpar, t.variance,
+                                t.variance + (include_noise ? t.noise : 0.0)};
+      double* dm = dout + (int64_t)(i & 1) * 2 * ns;
+      if ((rc = exact_predict_inverse(h, src, dxs, ns, dm, dm + ns, tile))) return rc;
+      HIPCHK(h, hipMemcpyAsync(means + (int64_t)i * ns, dm, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(vars + (int64_t)i * ns, dm + ns, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    // the single-cell views of the handle may point into the arena: their cached L^-1 is not this batch's
+    h->have_linv = false;
     return GPRX_OK;
   }
   static const bool no_sparse_batch = getenv("GPRX_NO_SPARSE_BATCH") != nullptr;

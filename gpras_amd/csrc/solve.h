@@ -200,6 +200,54 @@ inline hipError_t trtri_lower(hipStream_t st, const double* L, int64_t lda, cons
   return hipGetLastError();
 }
 
+// ---- in-place transpose of a square matrix (n x n, n a multiple of 64) ----------------------------------------
+// L^-1 (lower) -> L^-T (upper), so that K^-1 = L^-T L^-1 = Xt Xt^T runs as an NT product (both operands k-contiguous: the
+// LDS-DMA kernel, 58-60 TFLOP/s) instead of the TN form (both operands m-contiguous, 41 TFLOP/s).  One workgroup per tile
+// pair (ti >= tj): both 64 x 64 tiles go through one padded LDS image, 16-byte global accesses; 16 n^2 bytes of traffic.
+__global__ __launch_bounds__(256) void transpose_inplace_kernel(double* __restrict__ X, int64_t ld, int tiles, int64_t cs) {
+  __shared__ double sT[64][65];
+  X += (int64_t)blockIdx.y * cs;  // batched: blockIdx.y = cell
+  int bid = blockIdx.x;
+  int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+  while (ti * (ti + 1) / 2 > bid) --ti;
+  const int tj = bid - ti * (ti + 1) / 2;
+  (void)tiles;
+  double* A = X + (int64_t)ti * 64 * ld + tj * 64;  // tile (ti, tj)
+  double* B = X + (int64_t)tj * 64 * ld + ti * 64;  // tile (tj, ti)
+  const int tid = threadIdx.x;
+  d2 ra[8], rb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = tid + 256 * i, row = q >> 5, cc = q & 31;
+    ra[i] = *reinterpret_cast<const d2*>(A + (int64_t)row * ld + 2 * cc);
+    rb[i] = *reinterpret_cast<const d2*>(B + (int64_t)row * ld + 2 * cc);
+  }
+  auto through_lds = [&](const d2 (&src)[8], double* dst) {  // dst tile <- transpose of the tile held in src
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = tid + 256 * i, row = q >> 5, cc = q & 31;
+      sT[row][2 * cc] = src[i].x;
+      sT[row][2 * cc + 1] = src[i].y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = tid + 256 * i, row = q >> 5, cc = q & 31;
+      *reinterpret_cast<d2*>(dst + (int64_t)row * ld + 2 * cc) = d2{sT[2 * cc][row], sT[2 * cc + 1][row]};
+    }
+  };
+  through_lds(ra, B);
+  if (ti != tj) through_lds(rb, A);
+}
+
+inline hipError_t transpose_inplace(hipStream_t st, double* X, int64_t ld, int n, int cells = 1, int64_t cs = 0) {
+  const int tiles = n / 64;
+  hipLaunchKernelGGL(transpose_inplace_kernel, dim3(tiles * (tiles + 1) / 2, cells), dim3(256), 0, st, X, ld, tiles, cs);
+  return hipGetLastError();
+}
+
 // ---- reductions ----------------------------------------------------------------------------------
 // out[0] = sum_i log L[i,i] (i < n), out[1] = sum_i v[i]^2 (i < n)
 __global__ __launch_bounds__(256) void logdet_quad_kernel(const double* __restrict__ L, int64_t lda, const double* __restrict__ v, int n,
@@ -278,6 +326,17 @@ __global__ __launch_bounds__(256) void colreduce_final(const double* __restrict_
   double s = 0.0;
   for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * ncols + t];
   out[t] = (accumulate ? out[t] : base) + scale * s;
+}
+
+// out[row] = base - sum over the `nparts` slabs of partial[part * ld + row]  (the row sums of squares a GEMM launch with
+// GemmArgs::rowsq left behind), fixed order
+__global__ __launch_bounds__(256) void rowsq_final_kernel(const double* __restrict__ partial, int nparts, int64_t ld, int nrows, double base,
+                                                          double* __restrict__ out) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= nrows) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * ld + row];
+  out[row] = base - s;
 }
 
 // out[row] = base + scale * sum_c (w ? w[c] * M[row, c] : M[row, c]^2): one wave per row, 16-byte loads along the row
