@@ -42,7 +42,7 @@ struct TraceArgs {
 // One workgroup per 64 x 64 tile.  Thread mapping as kmat_kernel: 8 rows x 2 columns per thread.
 // Output per workgroup (deterministic two-stage reduction, no atomics):
 //   partial[wg][0] = sum w g          partial[wg][1] = sum_{i == j} w      partial[wg][2 + k] = -sum w v h ds_k^2 / l_k
-template <int KID>
+template <int KID, int FORM = 0>
 __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
   __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
@@ -93,13 +93,13 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
   double r2[8][2];
 #pragma unroll
   for (int it = 0; it < 8; ++it) r2[it][0] = r2[it][1] = 0.0;
-  double na[8], nb[2] = {0.0, 0.0};  // expanded form only (kmat.h)
+  double na[FORM ? 8 : 1], nb[2] = {0.0, 0.0};  // expanded form only (kmat.h)
 #pragma unroll
-  for (int it = 0; it < 8; ++it) na[it] = 0.0;
+  for (int it = 0; it < (FORM ? 8 : 1); ++it) na[it] = 0.0;
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
     stage(k0);
     __syncthreads();
-    if (p.form == 0) {
+    if constexpr (FORM == 0) {
 #pragma unroll
       for (int kk = 0; kk < KM_DC; ++kk) {
         const d2 bv = *reinterpret_cast<const d2*>(&sBt[kk][2 * cp]);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
     }
     __syncthreads();
   }
-  if (p.form != 0) {
+  if constexpr (FORM != 0) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       r2[it][0] = expanded_r2(na[it], nb[0], r2[it][0]);
@@ -259,14 +259,22 @@ __global__ __launch_bounds__(64) void trace_final(const double* __restrict__ par
 
 inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid, int cells = 1) {
   dim3 g(grid, cells), b(256);
+#define GPRX_TRACE_CASE(K_)                                                   \
+  case K_:                                                                    \
+    if (p.form)                                                               \
+      hipLaunchKernelGGL((trace_kernel<K_, 1>), g, b, 0, st, p);              \
+    else                                                                      \
+      hipLaunchKernelGGL((trace_kernel<K_, 0>), g, b, 0, st, p);              \
+    break;
   switch (kid) {
-    case 0: hipLaunchKernelGGL(trace_kernel<0>, g, b, 0, st, p); break;
-    case 1: hipLaunchKernelGGL(trace_kernel<1>, g, b, 0, st, p); break;
-    case 2: hipLaunchKernelGGL(trace_kernel<2>, g, b, 0, st, p); break;
-    case 3: hipLaunchKernelGGL(trace_kernel<3>, g, b, 0, st, p); break;
-    case 4: hipLaunchKernelGGL(trace_kernel<4>, g, b, 0, st, p); break;
+    GPRX_TRACE_CASE(0)
+    GPRX_TRACE_CASE(1)
+    GPRX_TRACE_CASE(2)
+    GPRX_TRACE_CASE(3)
+    GPRX_TRACE_CASE(4)
     default: return hipErrorInvalidValue;
   }
+#undef GPRX_TRACE_CASE
   return hipGetLastError();
 }
 

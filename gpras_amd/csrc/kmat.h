@@ -108,7 +108,9 @@ constexpr int CELL_PAR_LS = 8;
 
 // Stage KM_DC scaled coordinates of 64 points: sA[point][KM_DC] (row broadcast reads),
 // sBt[KM_DC][64] (lane-contiguous reads).
-template <int KID>
+// FORM (compile time: the default difference form keeps the registers and code of the kernel it always was -- as a run-time
+// branch the expanded form's extra accumulators cost the default path 50 %: 2.8 -> 4.2 ms for 128 cells of N = 4096)
+template <int KID, int FORM = 0>
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
   __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   double acc[8][2];
 #pragma unroll
   for (int it = 0; it < 8; ++it) acc[it][0] = acc[it][1] = 0.0;
-  double na[8], nb[2] = {0.0, 0.0};  // expanded form only: squared norms of this thread's 8 row points / 2 column points
+  double na[FORM ? 8 : 1], nb[2] = {0.0, 0.0};  // expanded form only: squared norms of this thread's 8 row points / 2 column points
 #pragma unroll
-  for (int it = 0; it < 8; ++it) na[it] = 0.0;
+  for (int it = 0; it < (FORM ? 8 : 1); ++it) na[it] = 0.0;
 
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
     // 64 points x 8 coords for each side = 512 + 512 values, 256 threads -> 2 + 2 each
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
       b0[kk] = v.x;
       b1[kk] = v.y;
     }
-    if (p.form == 0) {
+    if constexpr (FORM == 0) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = wave * 16 + 2 * it + rsub;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
     }
     __syncthreads();
   }
-  if (p.form != 0) {
+  if constexpr (FORM != 0) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       acc[it][0] = expanded_r2(na[it], nb[0], acc[it][0]);
@@ -221,14 +223,22 @@ inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p, int batch = 1
   p.tiles_n = (p.n2p + KM_T - 1) / KM_T;
   if (tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
   dim3 grid(tiles_m * p.tiles_n, batch), block(256);
+#define GPRX_KMAT_CASE(K_)                                                          \
+  case K_:                                                                          \
+    if (p.form)                                                                     \
+      hipLaunchKernelGGL((kmat_kernel<K_, 1>), grid, block, 0, st, p);              \
+    else                                                                            \
+      hipLaunchKernelGGL((kmat_kernel<K_, 0>), grid, block, 0, st, p);              \
+    break;
   switch (kid) {
-    case 0: hipLaunchKernelGGL(kmat_kernel<0>, grid, block, 0, st, p); break;
-    case 1: hipLaunchKernelGGL(kmat_kernel<1>, grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL(kmat_kernel<2>, grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL(kmat_kernel<3>, grid, block, 0, st, p); break;
-    case 4: hipLaunchKernelGGL(kmat_kernel<4>, grid, block, 0, st, p); break;
+    GPRX_KMAT_CASE(0)
+    GPRX_KMAT_CASE(1)
+    GPRX_KMAT_CASE(2)
+    GPRX_KMAT_CASE(3)
+    GPRX_KMAT_CASE(4)
     default: return hipErrorInvalidValue;
   }
+#undef GPRX_KMAT_CASE
   return hipGetLastError();
 }
 
