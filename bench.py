@@ -109,7 +109,20 @@ def main():
         # buffers); torch.distributed only launches the ranks, carries the 128-byte RCCL id and provides the timing barrier
         from gpras_amd.comm import Communicator
 
-        comm = Communicator.bootstrap(device, rank, world)
+        # (every rank must take the same path: the outcome of the communicator's creation is agreed through the process group,
+        # and a failure -- which cannot be rehearsed with more than one GPU here -- degrades to torch.distributed's all_gather
+        # instead of costing the whole scaling record; the JSON line says which collective ran)
+        comm_error = ""
+        try:
+            comm = Communicator.bootstrap(device, rank, world)
+        except Exception as exc:  # noqa: BLE001
+            comm, comm_error = None, f"{type(exc).__name__}: {exc}"
+        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            comm_error = comm_error or "another rank could not create its communicator"
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
     # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
@@ -157,15 +170,22 @@ def main():
         fit_step()
     if distributed:
         # the single collective of the job: every rank's results gathered over RCCL (gprx_comm_all_gather, device buffers)
-        check(lib.gprx_memcpy_h2d(device, d_mine.ptr, ptr(losses), losses.nbytes))
-        comm.all_gather_dev(d_mine, d_all, cells)
-        comm.synchronize()
+        if comm is not None:
+            check(lib.gprx_memcpy_h2d(device, d_mine.ptr, ptr(losses), losses.nbytes))
+            comm.all_gather_dev(d_mine, d_all, cells)
+            comm.synchronize()
+        else:
+            mine = torch.tensor(losses, dtype=torch.float64, device=f"cuda:{local_rank}")
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
-        all_losses = d_all.to_array((world, cells))
+        all_losses = d_all.to_array((world, cells)) if comm is not None else torch.stack(gathered).cpu().numpy()
         assert np.array_equal(all_losses[rank], losses) and np.all(np.isfinite(all_losses))
-        elapsed = comm.max(elapsed)  # the slowest rank's time
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())  # the slowest rank's time
     fits_per_s = world * cells * args.steps / elapsed
 
     result = {
@@ -187,7 +207,9 @@ def main():
             "d": DIM,
             "kernel": "RBF",
             "cells_per_gpu_per_step": cells,
-            "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end (gprx_comm_all_gather, device-resident)",
+            "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end",
+            "collective": ("none (one process)" if not distributed else "gprx_comm_all_gather (RCCL behind the C ABI, device-resident buffers)" if comm is not None
+                           else f"torch.distributed all_gather (fallback: {comm_error})"),
         },
     }
 
@@ -527,7 +549,8 @@ def main():
 
     lib.gprx_destroy(h)
     if distributed:
-        comm.close()
+        if comm is not None:
+            comm.close()
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()

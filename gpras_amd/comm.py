@@ -63,8 +63,15 @@ class Communicator:
         except ImportError:
             pass
         if dist is not None:
-            box = [new_unique_id() if rank == 0 else None]
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [new_unique_id()]
+                except Exception as exc:  # noqa: BLE001  (the other ranks wait in the broadcast: they must hear about it)
+                    box = [exc]
             dist.broadcast_object_list(box, src=0)
+            if isinstance(box[0], Exception):
+                raise RuntimeError(f"rank 0 could not create the RCCL id: {box[0]}")
             return cls(device, rank, world, box[0])
         if world == 1:
             return cls(device, 0, 1, new_unique_id())
