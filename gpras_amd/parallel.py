@@ -50,8 +50,21 @@ def communicator(device: int | None = None):
         from .comm import Communicator
 
         dev = torch.cuda.current_device() if device is None else device
-        _COMM = Communicator.bootstrap(dev, dist.get_rank(), dist.get_world_size())
-    return _COMM
+        try:
+            comm = Communicator.bootstrap(dev, dist.get_rank(), dist.get_world_size())
+        except Exception as exc:  # noqa: BLE001
+            import warnings
+
+            warnings.warn(f"gprx communicator unavailable ({exc}); the gather goes through torch.distributed", stacklevel=2)
+            comm = None
+        # every rank takes the same path: agree on the outcome through the process group
+        ok = torch.tensor([1 if comm is not None else 0], device=torch.device("cuda", dev))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+        _COMM = comm if comm is not None else False
+    return _COMM or None
 
 
 def _all_gather_array(arr: np.ndarray) -> list[np.ndarray]:
@@ -63,10 +76,11 @@ def _all_gather_array(arr: np.ndarray) -> list[np.ndarray]:
     import torch
 
     dist = _dist()
-    mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(device)
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
-    return [t.numpy() for t in out]
+    return [t.cpu().numpy() for t in out]
 
 
 class ShardedGPRAS(GPRAS):
