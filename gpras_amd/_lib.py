@@ -49,6 +49,7 @@ PROTOTYPES = {
     "gprx_select_slot": (C.c_int, [_vp, C.c_int]),
     "gprx_last_batch_ms": (C.c_int, [_vp, _dp]),
     "gprx_predict_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int]),
+    "gprx_predict_batch_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_predict": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_predict_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_last_timings": (C.c_int, [_vp, _dp]),
@@ -80,6 +81,9 @@ PROTOTYPES = {
     "gprx_pca_transform_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gprx_pca_reverse_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "gprx_pca_synchronize": (C.c_int, [_vp]),
+    "gprx_pca_to_depth_dev": (C.c_int, [_vp, _vp, _i64, C.c_int]),
+    "gprx_pca_sqrt_dev": (C.c_int, [_vp, _vp, _i64]),
+    "gprx_pca_transpose_dev": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "gprx_metrics": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "gprx_metrics_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "gprx_kmeans_lloyd": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _ip]),

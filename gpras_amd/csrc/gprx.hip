@@ -1708,11 +1708,13 @@ int gprx_predict(gprx_handle h, const double* xs, int64_t ns, double* mean, doub
 }
 
 // ---- device memory helpers ---------------------------------------------------------------------
-int gprx_predict_batch(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
-                       double* means, double* vars, int include_noise) {
+// Core of gprx_predict_batch: the test points are in device memory (xs_dev) and the results go to device memory
+// (means_dev / vars_dev: (count, ns) row-major); asynchronous on the handle's stream after the batched factorisation.
+static int predict_batch_core(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs_dev, int64_t ns,
+                              double* means_dev, double* vars_dev, int include_noise) {
   int rc;
-  if ((rc = check_handle(h))) return rc;
-  if (count <= 0 || !units || !thetas || ns < 0 || (ns > 0 && (!xs || !means || !vars))) return fail(h, GPRX_EINVAL, "null argument");
+  static const bool no_sparse_batch = getenv("GPRX_NO_SPARSE_BATCH") != nullptr;
+  hipStream_t st = h->stream;
   if (h->m == 0 && h->d <= CELL_PAR - CELL_PAR_LS) {
     // exact models: all factorisations by one batched launch sequence, then every slot predicts
     if ((rc = gprx_factorize_batch(h, count, units, thetas, 0, nullptr, nullptr))) return rc;
@@ -1721,22 +1723,17 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
     if (!use_inverse) {
       for (int i = 0; i < count; ++i) {
         if ((rc = select_slot(h, i))) return rc;
-        if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
+        if ((rc = gprx_predict_dev(h, xs_dev, ns, means_dev + (int64_t)i * ns, vars_dev + (int64_t)i * ns, include_noise))) return rc;
       }
       return GPRX_OK;
     }
-    // the test points go up ONCE; L^-1 of every slot by batched launches (trtri_lower with the cell index in its grids);
-    // each slot then predicts with its alpha / L^-1 / row of the parameter table -- no per-cell upload or synchronisation
+    // L^-1 of every slot by batched launches (trtri_lower with the cell index in its grids); each slot then predicts with
+    // its alpha / L^-1 / row of the parameter table -- no per-cell upload or synchronisation
     const int np = (int)h->np;
     const int64_t ld = h->np, cs = h->cell_stride, gs = 2 * (int64_t)h->np * h->np;
     const int tile = (int)std::min<int64_t>(PRED_TILE, round_up(ns, NB));
-    hipStream_t st = h->stream;
     if ((rc = ensure(h, h->garena, sizeof(double) * (size_t)gs * count))) return rc;
     if ((rc = ensure(h, h->Ks, sizeof(double) * h->np * tile * 2))) return rc;
-    if ((rc = ensure(h, h->xs, sizeof(double) * (ns * h->d + 4 * ns)))) return rc;
-    double* dxs = h->xs.p;
-    double* dout = dxs + ns * h->d;  // two (mean, var) staging pairs, used alternately (everything is ordered on the one stream)
-    HIPCHK(h, hipMemcpyAsync(dxs, xs, sizeof(double) * ns * h->d, hipMemcpyHostToDevice, st));
     for (int c = 0; c < count; ++c) HIPCHK(h, hipMemsetAsync(h->garena.p + (int64_t)c * gs, 0, sizeof(double) * h->np * ld, st));
     HIPCHK(h, trtri_lower(st, h->arena.p, ld, h->arena.p + h->off_invd, h->garena.p, ld, h->garena.p + (int64_t)np * ld, ld, np, count, cs, gs,
                           h->tune.update_tile ? h->tune.update_tile : 64));
@@ -1745,17 +1742,11 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
       const double* cpar = h->cellpar.p + (int64_t)i * CELL_PAR;
       const ExactPredictSrc src{h->arena.p + (int64_t)i * cs + h->off_alpha, h->garena.p + (int64_t)i * gs, nullptr, cpar, t.variance,
                                 t.variance + (include_noise ? t.noise : 0.0)};
-      double* dm = dout + (int64_t)(i & 1) * 2 * ns;
-      if ((rc = exact_predict_inverse(h, src, dxs, ns, dm, dm + ns, tile))) return rc;
-      HIPCHK(h, hipMemcpyAsync(means + (int64_t)i * ns, dm, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
-      HIPCHK(h, hipMemcpyAsync(vars + (int64_t)i * ns, dm + ns, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+      if ((rc = exact_predict_inverse(h, src, xs_dev, ns, means_dev + (int64_t)i * ns, vars_dev + (int64_t)i * ns, tile))) return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(st));
-    // the single-cell views of the handle may point into the arena: their cached L^-1 is not this batch's
-    h->have_linv = false;
+    h->have_linv = false;  // the single-cell views of the handle may point into the arena: their cached L^-1 is not this batch's
     return GPRX_OK;
   }
-  static const bool no_sparse_batch = getenv("GPRX_NO_SPARSE_BATCH") != nullptr;
   if (h->m != 0 && count > 1 && h->d <= CELL_PAR - CELL_PAR_LS && !no_sparse_batch) {
     // sparse models (what gpras runs): every cell factorised by ONE batched launch sequence, then one batched predict
     if (!z) return fail(h, GPRX_EINVAL, "z (inducing inputs) is null for a sparse model");
@@ -1773,21 +1764,47 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
     std::vector<int> stv(count);
     if ((rc = sgpr_objective_batch(h, count, units, ts.data(), z, elbo.data(), nullptr, nullptr, stv.data()))) return rc;  // ENOTPD included
     if (ns == 0) return GPRX_OK;
-    if ((rc = ensure(h, h->xs, sizeof(double) * (ns * h->d + 2 * ns * count)))) return rc;
-    double* dxs = h->xs.p;
-    double* dmean = dxs + ns * h->d;
-    double* dvar = dmean + ns * count;
-    HIPCHK(h, hipMemcpyAsync(dxs, xs, sizeof(double) * ns * h->d, hipMemcpyHostToDevice, h->stream));
-    if ((rc = sgpr_predict_batch(h, count, dxs, ns, dmean, dvar, include_noise))) return rc;
-    HIPCHK(h, hipMemcpyAsync(means, dmean, sizeof(double) * ns * count, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(vars, dvar, sizeof(double) * ns * count, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GPRX_OK;
+    return sgpr_predict_batch(h, count, xs_dev, ns, means_dev, vars_dev, include_noise);
   }
   for (int i = 0; i < count; ++i) {
     if ((rc = objective_impl(h, units[i], thetas + (int64_t)i * h->ntheta, z ? z + (int64_t)i * h->m * h->d : nullptr, 0, nullptr, nullptr)))
       return rc;
-    if ((rc = gprx_predict(h, xs, ns, means + (int64_t)i * ns, vars + (int64_t)i * ns, include_noise))) return rc;
+    if ((rc = gprx_predict_dev(h, xs_dev, ns, means_dev + (int64_t)i * ns, vars_dev + (int64_t)i * ns, include_noise))) return rc;
+  }
+  return GPRX_OK;
+}
+
+int gprx_predict_batch_dev(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs_dev, int64_t ns,
+                           double* means_dev, double* vars_dev, int include_noise) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (count <= 0 || !units || !thetas || ns < 0 || (ns > 0 && (!xs_dev || !means_dev || !vars_dev))) return fail(h, GPRX_EINVAL, "null argument");
+  return predict_batch_core(h, count, units, thetas, z, xs_dev, ns, means_dev, vars_dev, include_noise);
+}
+
+int gprx_predict_batch(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
+                       double* means, double* vars, int include_noise) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (count <= 0 || !units || !thetas || ns < 0 || (ns > 0 && (!xs || !means || !vars))) return fail(h, GPRX_EINVAL, "null argument");
+  // the test points go up ONCE; the (count, ns) results come back in slabs of cells so that the device staging stays small
+  // at configs[3]'s size (100 000 points: 1.6 MB per cell)
+  const int slab = (int)std::max<int64_t>(1, std::min<int64_t>(count, ((int64_t)1 << 27) / std::max<int64_t>(2 * ns, 1)));
+  if ((rc = ensure(h, h->xs, sizeof(double) * (ns * h->d + 2 * ns * slab + 16)))) return rc;
+  double* dxs = h->xs.p;
+  double* dmean = dxs + ns * h->d;
+  double* dvar = dmean + ns * slab;
+  if (ns > 0) HIPCHK(h, hipMemcpyAsync(dxs, xs, sizeof(double) * ns * h->d, hipMemcpyHostToDevice, h->stream));
+  for (int c0 = 0; c0 < count; c0 += slab) {
+    const int cnt = std::min(slab, count - c0);
+    if ((rc = predict_batch_core(h, cnt, units + c0, thetas + (int64_t)c0 * h->ntheta, z ? z + (int64_t)c0 * h->m * h->d : nullptr, dxs, ns, dmean, dvar,
+                                 include_noise)))
+      return rc;
+    if (ns > 0) {
+      HIPCHK(h, hipMemcpyAsync(means + (int64_t)c0 * ns, dmean, sizeof(double) * ns * cnt, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(vars + (int64_t)c0 * ns, dvar, sizeof(double) * ns * cnt, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   return GPRX_OK;
 }
@@ -1930,6 +1947,38 @@ int gprx_pca_reverse_dev(gprx_pca_handle p, const double* mean_dev, const double
   else
     hipLaunchKernelGGL(pca_reverse_kernel<64>, grid, dim3(256), 0, p->stream, mean_dev, var_dev, rows, p->k, p->cells, (const double*)p->E.p, p->cells_p,
                        (const double*)p->wrev.p, (const double*)p->base.p, (const double*)p->xm.p, (const double*)p->xs.p, full_dev, vfull_dev);
+  PCACHK(p, hipGetLastError());
+  return GPRX_OK;
+}
+
+int gprx_pca_to_depth_dev(gprx_pca_handle p, double* field_dev, int64_t rows, int add_elevations_first) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (rows < 0 || (rows > 0 && !field_dev)) return pfail(p, GPRX_EINVAL, "null argument");
+  if (rows == 0) return GPRX_OK;
+  PCACHK(p, hipSetDevice(p->device));
+  hipLaunchKernelGGL(field_to_depth_kernel, dim3(4096), dim3(256), 0, p->stream, field_dev, rows, p->cells, (const double*)p->elev.p,
+                     add_elevations_first ? 1 : 0);
+  PCACHK(p, hipGetLastError());
+  return GPRX_OK;
+}
+
+int gprx_pca_sqrt_dev(gprx_pca_handle p, double* field_dev, int64_t count) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (count < 0 || (count > 0 && !field_dev)) return pfail(p, GPRX_EINVAL, "null argument");
+  if (count == 0) return GPRX_OK;
+  PCACHK(p, hipSetDevice(p->device));
+  hipLaunchKernelGGL(field_sqrt_kernel, dim3(4096), dim3(256), 0, p->stream, field_dev, count);
+  PCACHK(p, hipGetLastError());
+  return GPRX_OK;
+}
+
+int gprx_pca_transpose_dev(gprx_pca_handle p, const double* src_dev, int64_t rows, int64_t cols, double* dst_dev) {
+  if (!p) return pfail(p, GPRX_EINVAL, "null handle");
+  if (rows < 0 || cols < 0 || (rows * cols > 0 && (!src_dev || !dst_dev))) return pfail(p, GPRX_EINVAL, "null argument");
+  if (rows * cols == 0) return GPRX_OK;
+  PCACHK(p, hipSetDevice(p->device));
+  hipLaunchKernelGGL(transpose_small_kernel, dim3((unsigned)std::min<int64_t>((rows * cols + 255) / 256, 4096)), dim3(256), 0, p->stream, src_dev, rows,
+                     cols, dst_dev);
   PCACHK(p, hipGetLastError());
   return GPRX_OK;
 }

@@ -72,4 +72,34 @@ __global__ __launch_bounds__(256) void pca_reverse_kernel(const double* __restri
   }
 }
 
+// What production/analysis/pipeline.py:262-277 does to the reconstructed fields before the metrics, in place on the device:
+//   mode 1 ("depth" models):  y += elevations;  then wse_2_depth: y = max(y - elevations, 0)   (literally: (y + e) - e)
+//   mode 0 ("wse" models and the truth field):  y = max(y - elevations, 0)                     (PreProcessor.wse_2_depth, :1040-1044)
+// and  conf = sqrt(var)  (pipeline.py:286).
+__global__ __launch_bounds__(256) void field_to_depth_kernel(double* __restrict__ f, int64_t rows, int64_t cells, const double* __restrict__ elev,
+                                                            int add_first) {
+  const int64_t total = rows * cells;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const double el = elev[e % cells];
+    double v = f[e];
+    {
+#pragma clang fp contract(off)
+      if (add_first) v = v + el;
+      v = v - el;
+    }
+    f[e] = v < 0.0 ? 0.0 : v;  // d[d < 0] = 0: a NaN stays a NaN
+  }
+}
+__global__ __launch_bounds__(256) void field_sqrt_kernel(double* __restrict__ f, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) f[e] = sqrt(f[e]);
+}
+// dst (cols, rows) <- src (rows, cols)^T  (small: the (modes, points) block of a batched predict -> (points, modes))
+__global__ __launch_bounds__(256) void transpose_small_kernel(const double* __restrict__ src, int64_t rows, int64_t cols, double* __restrict__ dst) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t c = e / rows, r = e - c * rows;  // consecutive threads: consecutive r -> coalesced writes of dst row c
+    dst[c * rows + r] = src[r * cols + c];
+  }
+}
+
 }  // namespace gprx

@@ -202,6 +202,25 @@ class Engine:
         return means, variances
 
     @_locked
+    def predict_batch_dev(self, units, thetas, xs_dev, ns: int, means_dev, vars_dev, zs=None, include_noise: bool = True, wait: bool = True):
+        """``predict_batch`` with the test points and the ``(cells, N*)`` results in device memory (``gprx_predict_batch_dev``)."""
+        units = np.ascontiguousarray(units, dtype=np.int32)
+        thetas = as_f64(thetas)
+        if thetas.shape != (units.size, self.n_theta):
+            raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
+        zp = None
+        if self.m != 0:
+            zs = as_f64(zs)
+            if zs.shape != (units.size, self.m, self.d):
+                raise ValueError(f"zs must be ({units.size}, {self.m}, {self.d})")
+            zp = ptr(zs)
+        p = lambda b: b.ptr if hasattr(b, "ptr") else b  # noqa: E731
+        check(self._lib.gprx_predict_batch_dev(self._h, units.size, ptr(units), ptr(thetas), zp, p(xs_dev), int(ns), p(means_dev), p(vars_dev),
+                                               int(include_noise)), self._h)
+        if wait:
+            check(self._lib.gprx_synchronize(self._h), self._h)
+
+    @_locked
     def predict_dev(self, xs_dev, ns: int, mean_dev, var_dev, include_noise: bool = True, wait: bool = True):
         """The same with device pointers (``gprx_predict_dev``): inputs and outputs stay resident in HBM."""
         p = lambda b: b.ptr if hasattr(b, "ptr") else b  # noqa: E731

@@ -27,6 +27,16 @@ from . import _lib
 from ._lib import DeviceBuffer, as_f64, check, ptr
 
 
+class _View:
+    """A device pointer that is not owned (``free`` does nothing)."""
+
+    def __init__(self, p):
+        self.ptr = p.ptr if hasattr(p, "ptr") else p
+
+    def free(self):
+        pass
+
+
 class FieldMetrics:
     def __init__(self, x, y, conf=None, t_tol: int = 0, v_tol: float = 0.0, device: int = 0):
         x, y = as_f64(x), as_f64(y)
@@ -44,6 +54,28 @@ class FieldMetrics:
         self._dx = DeviceBuffer.from_array(x, device)
         self._dy = self._dx if y is x else DeviceBuffer.from_array(y, device)
         self._dc = None if conf is None else (self._dx if conf is x else DeviceBuffer.from_array(conf, device))
+        self._evaluate()
+
+    @classmethod
+    def from_device(cls, x_dev, y_dev, conf_dev, rows: int, cells: int, t_tol: int = 0, v_tol: float = 0.0, device: int = 0) -> "FieldMetrics":
+        """The same over fields that are ALREADY in device memory ((rows, cells) row-major float64; pointers or anything with a
+        ``.ptr``): nothing is uploaded and nothing is owned -- the caller keeps the buffers alive while the ``*_mts`` metrics
+        with caller-supplied timesteps may still gather from them (``gpras_amd.pipeline``)."""
+        self = cls.__new__(cls)
+        self.rows, self.cells = int(rows), int(cells)
+        if self.rows <= 0 or self.cells <= 0:
+            raise ValueError("x and y must be 2-D arrays of the same shape (timesteps, cells)")
+        self.t_tol, self.v_tol = int(t_tol), float(v_tol)
+        self.has_conf = conf_dev is not None
+        self.device = device
+        self._lib = _lib.load()
+        self._dx, self._dy = _View(x_dev), _View(y_dev)
+        self._dc = None if conf_dev is None else _View(conf_dev)
+        self._evaluate()
+        return self
+
+    def _evaluate(self):
+        device = self.device
         drow = DeviceBuffer(8 * self.rows * 4, device)
         dcell = DeviceBuffer(8 * self.cells * 5, device)
         darg = DeviceBuffer(4 * self.cells * 2, device)
@@ -179,8 +211,6 @@ def export_metric_summary(x_all, y_all, conf_all, out_path: str | Path, depth_th
     """Export all metrics to a sqlite database (metrics.py:11-82): same tables, columns and call pattern -- including the
     positional ``f2_mts(x, y, x_mts, y_mts)`` / ``f3_mts`` calls of metrics.py:56-57, where the cached argmax of x lands in
     the ``depth_threshold`` slot and that of y in the ``x_mts`` slot.  One fused device evaluation per event."""
-    import pandas as pd
-
     all_scalar, all_timeseries, all_cells = [], [], []
     for event in x_all.index.unique(level=0):
         x = x_all.loc[event].values
@@ -188,41 +218,58 @@ def export_metric_summary(x_all, y_all, conf_all, out_path: str | Path, depth_th
         conf = conf_all.loc[event].values
         tsteps = x_all.loc[event].index.values
         fm = FieldMetrics(x, y, conf, t_tol=t_tol, v_tol=v_tol, device=device)
-        x_mts, y_mts = fm.x_mts, fm.y_mts  # np.argmax(x, axis=0), np.argmax(y, axis=0) (metrics.py:35-36), from the fused pass
-        wet = hydraulic_parameter != "velocity"
-        scalar_dict = {
-            "event": event,
-            "rmse_aoi_toi": [fm.rmse_aoi_toi()],
-            "mae_aoi_toi": [fm.mae_aoi_toi()],
-            "conf_aoi_toi": [fm.conf_aoi_toi()],
-            "rmse_aoi_mts": [fm.rmse_aoi_mts(x_mts, y_mts)],
-            "nse_aoi_mts": [fm.nse_aoi_mts(x_mts, y_mts)],
-            "err_aoi_toi": [fm.err_aoi_toi()],
-            "err_aoi_mts": [fm.err_aoi_mts(x_mts, y_mts)],
-            "fi_aoi_toi": [fm.fi_aoi_toi()],
-            "pod_mts": [fm.pod_mts(depth_threshold, x_mts, y_mts)] if wet else [np.nan],
-            "rfa_mts": [fm.rfa_mts(depth_threshold, x_mts, y_mts)] if wet else [np.nan],
-            "csi_mts": [fm.csi_mts(depth_threshold, x_mts, y_mts)] if wet else [np.nan],
-            "f2_mts": [fm.f2_mts(x_mts, y_mts)],  # positional, as the reference: threshold = x_mts, x_mts = y_mts
-            "f3_mts": [fm.f3_mts(x_mts, y_mts)],
-        }
-        all_scalar.append(pd.DataFrame.from_dict(scalar_dict))
-        all_timeseries.append(pd.DataFrame.from_dict({
-            "event": np.repeat(event, x.shape[0]),
-            "timestep": tsteps,
-            "rmse_aoi_ts": fm.rmse_aoi_ts(),
-            "err_aoi_ts": fm.err_aoi_ts(),
-            "conf_aoi_ts": fm.conf_aoi_ts(),
-        }))
-        all_cells.append(pd.DataFrame.from_dict({
-            "event": np.repeat(event, x.shape[1]),
-            "cell_id": x_all.columns,
-            "rmse_cell_toi": fm.rmse_cell_toi(),
-            "err_cell_mts": fm.err_cell_mts(x_mts, y_mts),
-            "err_cell_toi": fm.err_cell_toi(),
-            "conf_cell_toi": fm.conf_cell_toi(),
-        }))
+        scalar, series, cells = event_tables(fm, event, tsteps, x_all.columns, depth_threshold, hydraulic_parameter)
+        all_scalar.append(scalar)
+        all_timeseries.append(series)
+        all_cells.append(cells)
         fm.close()
+    write_metric_db(all_scalar, all_timeseries, all_cells, out_path)
+
+
+def event_tables(fm: FieldMetrics, event, tsteps, columns, depth_threshold: float = 0.5, hydraulic_parameter: str = "depth"):
+    """The three data frames of one event (metrics.py:31-76) from its fused evaluation ``fm``."""
+    import pandas as pd
+
+    x_mts, y_mts = fm.x_mts, fm.y_mts  # np.argmax(x, axis=0), np.argmax(y, axis=0) (metrics.py:35-36), from the fused pass
+    wet = hydraulic_parameter != "velocity"
+    scalar_dict = {
+        "event": event,
+        "rmse_aoi_toi": [fm.rmse_aoi_toi()],
+        "mae_aoi_toi": [fm.mae_aoi_toi()],
+        "conf_aoi_toi": [fm.conf_aoi_toi()],
+        "rmse_aoi_mts": [fm.rmse_aoi_mts(x_mts, y_mts)],
+        "nse_aoi_mts": [fm.nse_aoi_mts(x_mts, y_mts)],
+        "err_aoi_toi": [fm.err_aoi_toi()],
+        "err_aoi_mts": [fm.err_aoi_mts(x_mts, y_mts)],
+        "fi_aoi_toi": [fm.fi_aoi_toi()],
+        "pod_mts": [fm.pod_mts(depth_threshold, x_mts, y_mts)] if wet else [np.nan],
+        "rfa_mts": [fm.rfa_mts(depth_threshold, x_mts, y_mts)] if wet else [np.nan],
+        "csi_mts": [fm.csi_mts(depth_threshold, x_mts, y_mts)] if wet else [np.nan],
+        "f2_mts": [fm.f2_mts(x_mts, y_mts)],  # positional, as the reference: threshold = x_mts, x_mts = y_mts
+        "f3_mts": [fm.f3_mts(x_mts, y_mts)],
+    }
+    scalar = pd.DataFrame.from_dict(scalar_dict)
+    series = pd.DataFrame.from_dict({
+        "event": np.repeat(event, fm.rows),
+        "timestep": tsteps,
+        "rmse_aoi_ts": fm.rmse_aoi_ts(),
+        "err_aoi_ts": fm.err_aoi_ts(),
+        "conf_aoi_ts": fm.conf_aoi_ts(),
+    })
+    cells = pd.DataFrame.from_dict({
+        "event": np.repeat(event, fm.cells),
+        "cell_id": columns,
+        "rmse_cell_toi": fm.rmse_cell_toi(),
+        "err_cell_mts": fm.err_cell_mts(x_mts, y_mts),
+        "err_cell_toi": fm.err_cell_toi(),
+        "conf_cell_toi": fm.conf_cell_toi(),
+    })
+    return scalar, series, cells
+
+
+def write_metric_db(all_scalar, all_timeseries, all_cells, out_path) -> None:
+    import pandas as pd
+
     with sqlite3.connect(out_path) as con:
         pd.concat(all_scalar).to_sql("scalar_metrics", con, index=False, if_exists="replace")
         pd.concat(all_timeseries).to_sql("timeseries_metrics", con, index=False, if_exists="replace")

@@ -240,6 +240,12 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
 int gprx_predict_batch(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
                        double* means, double* vars, int include_noise);
 
+/* The same with the test points and the results in DEVICE memory (means_dev / vars_dev: (count, ns) row-major), asynchronous
+ * on the handle's stream once the batched factorisation has returned: predictions that stay in HBM for the reverse
+ * projection and the metrics (production/analysis/pipeline.py:260-288). */
+int gprx_predict_batch_dev(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs_dev, int64_t ns,
+                           double* means_dev, double* vars_dev, int include_noise);
+
 /* ---- EOF (PCA) projection either side of the GP path: SURVEY.md section 8(f) row N1 ------------------- */
 /* One projector = the fitted state of a reference PreProcessor (gpras/preprocess.py:868-927): `dry` (n_cells bytes, 1 =
  * always-dry cell, may be NULL = none), `elevations` (n_cells, needed for depth mode and for filling dry cells in wse mode),
@@ -261,6 +267,14 @@ int gprx_pca_reverse(gprx_pca_handle p, const double* mean, const double* var, i
 int gprx_pca_transform_dev(gprx_pca_handle p, const double* x_dev, int64_t rows, double* z_dev);
 int gprx_pca_reverse_dev(gprx_pca_handle p, const double* mean_dev, const double* var_dev, int64_t rows, double* full_dev, double* vfull_dev);
 int gprx_pca_synchronize(gprx_pca_handle p);
+/* What production/analysis/pipeline.py:262-277 and :286 do to the reconstructed fields before the metrics, in place on the
+ * device and on the projector's stream:  to_depth -- field (rows, n_cells): add_elevations_first != 0 ("depth" models:
+ * y += elevations, then wse_2_depth) computes max((y + e) - e, 0), else max(y - e, 0) (PreProcessor.wse_2_depth,
+ * preprocess.py:1040-1044; also for the truth field);  sqrt -- conf = sqrt(var) over `count` values;  transpose -- dst (cols,
+ * rows) = src (rows, cols)^T, e.g. the (modes, points) block of gprx_predict_batch_dev into reverse's (points, modes). */
+int gprx_pca_to_depth_dev(gprx_pca_handle p, double* field_dev, int64_t rows, int add_elevations_first);
+int gprx_pca_sqrt_dev(gprx_pca_handle p, double* field_dev, int64_t count);
+int gprx_pca_transpose_dev(gprx_pca_handle p, const double* src_dev, int64_t rows, int64_t cols, double* dst_dev);
 
 /* ---- fused error metrics over two fields: SURVEY.md section 8(f) row N3 (gpras/metrics.py:85-318) ---------- */
 /* Two streaming passes over x (truth), y (prediction) and conf (may be NULL), each (rows, cells) row-major, yield every
