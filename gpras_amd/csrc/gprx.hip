@@ -71,6 +71,8 @@ struct gprx_ctx {
                           // [74] variance, [75] noise (graph replay reads them through the device block `gparams`)
   double* gparams = nullptr;            // device {variance, noise} for captured kernel-matrix builds
   std::map<int, hipGraphExec_t> graphs;  // unit -> captured single-stream exact factorisation
+  std::map<std::pair<int, int>, hipGraphExec_t> sgraphs;  // (cells, with gradient) -> captured sparse batch evaluation
+  bool sgraph_off = false;                                // a capture failed once: this handle stays on eager launches
   // current factorisation
   bool factorized = false;
   bool have_linv = false;  // Xinv holds L^-1 of the current factorisation (exact path)
@@ -435,6 +437,8 @@ __global__ void copy_row_batch_kernel(const double* src, double* dst, int n, int
 void drop_graphs(gprx_handle h) {
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
   h->graphs.clear();
+  for (auto& kv : h->sgraphs) hipGraphExecDestroy(kv.second);
+  h->sgraphs.clear();
 }
 
 // views of the single-cell buffers into the arena are invalid once it moves
@@ -853,7 +857,7 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   HIPCHK(h, launch_trace(st, h->kid, with_form(tq, h), tiles_m * tiles_m));
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums);
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width);
-  hipLaunchKernelGGL(dz_kernel, dim3(m * d), dim3(256), 0, st, (const double*)h->Z.p, (const double*)h->X.p, (const double*)h->WHP.p,
+  hipLaunchKernelGGL(dz_kernel, dim3(dz_grid(m, d)), dim3(256), 0, st, (const double*)h->Z.p, (const double*)h->X.p, (const double*)h->WHP.p,
                      (int64_t)np, (const double*)h->WHQ.p, (int64_t)mp, (const double*)h->invls.p, m, n, d, h->dZ.p);
   // noise terms: |y - P^T m|^2 and tr(B^-1) = |LB^-1|_F^2
   HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, h->P.p, np, mvec, 1, 0.0, qvec, 1, 0, 64));
@@ -940,6 +944,7 @@ SgprLayout sgpr_batch_layout(gprx_handle h) {
 int ensure_sarena(gprx_handle h, int slots, const SgprLayout& L) {
   if (h->sarena_slots >= slots) return GPRX_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  drop_graphs(h);  // captured evaluations hold the addresses of the buffers released below
   if (h->sarena.p) HIPCHK(h, hipFree(h->sarena.p));
   h->sarena.p = nullptr;
   h->sarena.bytes = 0;
@@ -949,7 +954,7 @@ int ensure_sarena(gprx_handle h, int slots, const SgprLayout& L) {
   HIPCHK(h, hipMemset(h->sarena.p, 0, sizeof(double) * (size_t)L.ss * slots));  // padding of every matrix stays zero
   if ((rc = ensure(h, h->cellpar, sizeof(double) * CELL_PAR * slots))) return rc;
   if ((rc = ensure(h, h->cellres, sizeof(double) * CELL_RES * slots))) return rc;
-  const size_t need = (size_t)slots * (CELL_PAR + CELL_RES + 8 + 2 * L.width + h->m * h->d);
+  const size_t need = (size_t)slots * (CELL_PAR + CELL_RES + 8 + 2 * L.width + 2 * h->m * h->d);
   if (h->spin_doubles < need) {
     if (h->spin) HIPCHK(h, hipHostFree(h->spin));
     h->spin = nullptr;
@@ -960,34 +965,42 @@ int ensure_sarena(gprx_handle h, int slots, const SgprLayout& L) {
   return GPRX_OK;
 }
 
-// elbo_out[c] (NaN if a Cholesky failed), g: count x ntheta constrained-parameter derivatives, gz: count x m x d (host);
-// g / gz may be null (loss only).  status[c]: GPRX_OK / GPRX_ENOTPD.
-int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta* ts, const double* zs, double* elbo_out, double* g, double* gz,
-                         int* status) {
-  const SgprLayout L = sgpr_batch_layout(h);
-  int rc;
-  if ((rc = ensure_sarena(h, count, L))) return rc;
+// Pinned staging block of the sparse batch (h->spin), offsets in doubles for `count` cells.
+struct SgprStage {
+  size_t par, res, red, sum, dz, z;
+};
+SgprStage sgpr_stage(gprx_handle h, int count, const SgprLayout& L) {
+  SgprStage s{};
+  s.par = 0;
+  s.res = s.par + (size_t)count * CELL_PAR;
+  s.red = s.res + (size_t)count * CELL_RES;
+  s.sum = s.red + (size_t)count * 8;
+  s.dz = s.sum + (size_t)count * 2 * L.width;
+  s.z = s.dz + (size_t)count * h->m * h->d;
+  return s;
+}
+
+// Device part of one batched evaluation: everything between the staged inputs (parameter table and Z in pinned memory) and
+// the staged outputs (pivot status, reductions, trace sums, dZ in pinned memory).  Nothing here depends on the VALUES of the
+// parameters -- they travel through the cell-parameter table -- so the sequence is captured once per (cells, gradient) into a
+// hipGraph and replayed (sgpr_objective_batch): ~45 launches whose enqueue cost, not their device time, bounded a step.
+int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_grad) {
   const int mp = (int)h->mp, np = (int)h->np, m = (int)h->m, n = (int)h->n, d = h->d;
   const int64_t ss = L.ss, mm = (int64_t)mp * mp;
   const size_t pitch = sizeof(double) * (size_t)ss;
   hipStream_t st = h->stream;
   double* A0 = h->sarena.p;
-  double* par = h->spin;
-  for (int c = 0; c < count; ++c) {
-    double* row = par + (size_t)c * CELL_PAR;
-    std::memset(row, 0, sizeof(double) * CELL_PAR);
-    row[0] = ts[c].variance;
-    row[1] = ts[c].noise;
-    row[2] = (double)units[c];
-    row[3] = 1.0 / ts[c].noise;
-    for (int k = 0; k < d; ++k) row[CELL_PAR_LS + k] = ts[c].ls[k];
-  }
-  HIPCHK(h, hipMemcpyAsync(h->cellpar.p, par, sizeof(double) * CELL_PAR * count, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemsetAsync(h->cellres.p, 0, sizeof(double) * CELL_RES * count, st));
-  HIPCHK(h, hipMemcpy2DAsync(A0 + L.oZ, pitch, zs, sizeof(double) * m * d, sizeof(double) * m * d, count, hipMemcpyHostToDevice, st));
+  const SgprStage sg = sgpr_stage(h, count, L);
+  // (Tried: the independent branches of the evaluation -- Kuf beside Kuu's factorisation; R, Sinv / T2, T1 / Qinv, m; the
+  // two contractions and the noise terms -- on side streams, i.e. parallel branches of the captured graph.  The dependent chain
+  // drops from 34 to 20 launches, but every cross-branch edge costs more than an in-order kernel boundary on this runtime:
+  // 16 cells 0.427 ms against 0.400 ms serial.  One stream it is.)
   const double* cpar = h->cellpar.p;
   const double* inv_s = cpar + 3;  // alpha table: 1 / s, CELL_PAR apart
-  hipLaunchKernelGGL(gather_y_kernel, dim3((np + 255) / 256, count), dim3(256), 0, st, (const double*)h->Y.p, np, cpar, CELL_PAR, A0 + L.oY, ss);
+  static_assert(CELL_RES <= 256 && CELL_PAR <= 256, "sgpr_stage_in_kernel moves them with its first workgroup");
+  hipLaunchKernelGGL(sgpr_stage_in_kernel, dim3((std::max(np, m * d) + 255) / 256, count), dim3(256), 0, st, (const double*)h->Y.p, np,
+                     (const double*)(h->spin + sg.par), CELL_PAR, h->cellpar.p, (const double*)(h->spin + sg.z), m * d, A0 + L.oZ, A0 + L.oY, ss,
+                     h->cellres.p, CELL_RES);
   // ---- factorisation (sgpr_factorize) ----
   KmatArgs kp{A0 + L.oZ, h->X.p, nullptr, A0 + L.oP, np, m, n, d, mp, np, 0.0, 0.0, 0, 0.0, nullptr, 0};
   kp.cell_par = cpar;
@@ -1004,8 +1017,13 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   HIPCHK(h, launch_kmat(st, h->kid, with_form(kq, h), count));
   int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
   HIPCHK(h, potrf_lower(st, A0 + L.oQm, mp, mp, 0, A0 + L.oInvDL, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES, &h->tune));
-  HIPCHK(h, hipMemcpy2DAsync(A0 + L.oAm, pitch, A0 + L.oP, pitch, sizeof(double) * (size_t)mp * np, count, hipMemcpyDeviceToDevice, st));
-  HIPCHK(h, trsm_lower_left(st, A0 + L.oQm, mp, A0 + L.oInvDL, A0 + L.oAm, np, mp, np, count, ss));
+  const bool one_block = mp == NB;  // M <= 64 (the reference's default is 50): every M x M matrix is one 64 x 64 tile
+  if (one_block) {
+    HIPCHK(h, trsm_lower_left(st, A0 + L.oQm, mp, A0 + L.oInvDL, A0 + L.oAm, np, mp, np, count, ss, A0 + L.oP));  // A = L^-1 P straight from P
+  } else {
+    HIPCHK(h, hipMemcpy2DAsync(A0 + L.oAm, pitch, A0 + L.oP, pitch, sizeof(double) * (size_t)mp * np, count, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, trsm_lower_left(st, A0 + L.oQm, mp, A0 + L.oInvDL, A0 + L.oAm, np, mp, np, count, ss));
+  }
   if (mp <= 512 && np >= 4 * SPLITK_CHUNK) {
     HIPCHK(h, launch_gemm_splitk(st, 0, 1, mp, mp, np, 0.0, A0 + L.oAm, np, A0 + L.oAm, np, 0.0, A0 + L.oBm, mp, A0 + L.oWs, SPLITK_CHUNK, count, ss, ss,
                                  ss, ss, inv_s, CELL_PAR));
@@ -1013,13 +1031,17 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     HIPCHK(h, launch_gemm(st, 0, 1, mp, mp, np, 0.0, A0 + L.oAm, np, A0 + L.oAm, np, 0.0, A0 + L.oBm, mp, 0, 0, 1, 0, 0, 0, count, ss, ss, ss, inv_s,
                           CELL_PAR));
   }
-  hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256, count), dim3(256), 0, st, A0 + L.oBm, (int64_t)mp, mp, 1.0, ss);
-  hipLaunchKernelGGL(diag_sum_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, mp, 1.0, A0 + L.oRed + 2, ss);
   double* SM0 = A0 + L.oSM;
   auto smb = [&](int slot) { return SM0 + (size_t)slot * mm; };
-  HIPCHK(h, hipMemcpy2DAsync(smb(SM_BFULL), pitch, A0 + L.oBm, pitch, sizeof(double) * (size_t)mm, count, hipMemcpyDeviceToDevice, st));
   double* crow = A0 + L.oBm + mm;
-  HIPCHK(h, hipMemset2DAsync(crow, pitch, 0, sizeof(double) * (size_t)NB * mp, count, st));
+  if (mp <= 128) {
+    hipLaunchKernelGGL(sgpr_b_finish_kernel, dim3(count), dim3(256), 0, st, A0 + L.oBm, mp, A0 + L.oRed + 2, smb(SM_BFULL), ss);
+  } else {
+    hipLaunchKernelGGL(add_diag_kernel, dim3((mp + 255) / 256, count), dim3(256), 0, st, A0 + L.oBm, (int64_t)mp, mp, 1.0, ss);
+    hipLaunchKernelGGL(diag_sum_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, mp, 1.0, A0 + L.oRed + 2, ss);
+    HIPCHK(h, hipMemcpy2DAsync(smb(SM_BFULL), pitch, A0 + L.oBm, pitch, sizeof(double) * (size_t)mm, count, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemset2DAsync(crow, pitch, 0, sizeof(double) * (size_t)NB * mp, count, st));
+  }
   if (np >= 4 * SPLITK_CHUNK) {
     HIPCHK(h, launch_gemm_splitk(st, 0, 0, mp, 1, np, 0.0, A0 + L.oAm, np, A0 + L.oY, 1, 0.0, crow, 1, A0 + L.oWs, SPLITK_CHUNK, count, ss, ss, ss, ss,
                                  inv_s, CELL_PAR));
@@ -1027,10 +1049,14 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     HIPCHK(h, launch_gemm(st, 0, 0, mp, 1, np, 0.0, A0 + L.oAm, np, A0 + L.oY, 1, 0.0, crow, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss, inv_s, CELL_PAR));
   }
   HIPCHK(h, potrf_lower(st, A0 + L.oBm, mp, mp, NB, A0 + L.oInvDB, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES, &h->tune));
-  hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, (const double*)crow, mp,
-                     A0 + L.oRed, ss, (int)ss);
+  const bool fused_small = one_block && want_grad;  // sgpr_small_kernel: the M x M algebra of the gradient, and these two reductions with it
+  if (!fused_small)
+    hipLaunchKernelGGL(logdet_quad_kernel, dim3(count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (int64_t)mp, (const double*)crow, mp,
+                       A0 + L.oRed, ss, (int)ss);
   // ---- gradient (sgpr_gradient) ----
-  double *Linv = smb(SM_LINV), *LBinv = smb(SM_LBINV), *Qinv = smb(SM_QINV), *Sinv = smb(SM_SINV), *R = smb(SM_R), *T1 = smb(SM_T1),
+  // one block: L^-1 and LB^-1 ARE the inverses of the diagonal blocks that the factorisations left behind (trtri_lower would
+  // clear a matrix and copy them into it)
+  double *Linv = one_block ? A0 + L.oInvDL : smb(SM_LINV), *LBinv = one_block ? A0 + L.oInvDB : smb(SM_LBINV), *Qinv = smb(SM_QINV), *Sinv = smb(SM_SINV), *R = smb(SM_R), *T1 = smb(SM_T1),
          *T2 = smb(SM_T2), *W = smb(SM_W), *GQ = smb(SM_GQ), *Bfull = smb(SM_BFULL);
   double* mvec = A0 + L.oVecs;
   double* qvec = A0 + L.oVecs + 4 * mp;
@@ -1038,24 +1064,32 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   double* partQ = partP + L.part_p;
   double* sums = partQ + L.part_q;
   const int tiles_m = mp / KM_T, tiles_n = np / KM_T, width = L.width;
-  if (g) {
-    auto gemm_mm = [&](int ta, int tb, const double* A, const double* B, double* C, int flags) {
-      return launch_gemm(st, ta, tb, mp, mp, mp, 1.0, A, mp, B, mp, 0.0, C, mp, flags, 0, 1, 0, 0, 0, count, ss, ss, ss);
+  if (want_grad) {
+    auto gemm_mm = [&](hipStream_t sx, int ta, int tb, const double* A, const double* B, double* C, int flags) {
+      return launch_gemm(sx, ta, tb, mp, mp, mp, 1.0, A, mp, B, mp, 0.0, C, mp, flags, 0, 1, 0, 0, 0, count, ss, ss, ss);
     };
-    HIPCHK(h, hipMemset2DAsync(Linv, pitch, 0, sizeof(double) * (size_t)mm, count, st));
-    HIPCHK(h, trtri_lower(st, A0 + L.oQm, mp, A0 + L.oInvDL, Linv, mp, T1, mp, mp, count, ss, ss));
-    HIPCHK(h, hipMemset2DAsync(LBinv, pitch, 0, sizeof(double) * (size_t)mm, count, st));
-    HIPCHK(h, trtri_lower(st, A0 + L.oBm, mp, A0 + L.oInvDB, LBinv, mp, T1, mp, mp, count, ss, ss));
-    HIPCHK(h, gemm_mm(1, 0, Linv, Linv, Qinv, GEMM_A_UPPER | GEMM_B_LOWER));
-    HIPCHK(h, gemm_mm(0, 0, LBinv, Linv, R, GEMM_A_LOWER | GEMM_B_LOWER));
-    HIPCHK(h, gemm_mm(1, 0, R, R, Sinv, GEMM_A_UPPER | GEMM_B_LOWER));
-    HIPCHK(h, gemm_mm(0, 0, Bfull, Linv, T2, GEMM_B_LOWER));
-    HIPCHK(h, gemm_mm(1, 0, Linv, T2, T1, GEMM_A_UPPER));
-    hipLaunchKernelGGL(copy_row_batch_kernel, dim3((mp + 255) / 256, count), dim3(256), 0, st, (const double*)crow, mvec, mp, ss);
-    HIPCHK(h, trsv_lower(st, A0 + L.oBm, mp, A0 + L.oInvDB, mvec, mp, true, count, ss));
-    HIPCHK(h, trsv_lower(st, A0 + L.oQm, mp, A0 + L.oInvDL, mvec, mp, true, count, ss));
-    hipLaunchKernelGGL(sgpr_combine_kernel, dim3((mp * mp + 255) / 256, count), dim3(256), 0, st, (const double*)Qinv, (const double*)Sinv,
-                       (const double*)T1, (const double*)mvec, mp, W, GQ, ss);
+    if (fused_small) {
+      hipLaunchKernelGGL(sgpr_small_kernel, dim3(count), dim3(256), 0, st, (const double*)(A0 + L.oBm), (const double*)crow,
+                         (const double*)(A0 + L.oInvDL), (const double*)(A0 + L.oInvDB), (const double*)Bfull, A0 + L.oRed, mvec, W, GQ, ss);
+    } else {
+      if (!one_block) {
+        HIPCHK(h, hipMemset2DAsync(Linv, pitch, 0, sizeof(double) * (size_t)mm, count, st));
+        HIPCHK(h, trtri_lower(st, A0 + L.oQm, mp, A0 + L.oInvDL, Linv, mp, T1, mp, mp, count, ss, ss));
+        HIPCHK(h, hipMemset2DAsync(LBinv, pitch, 0, sizeof(double) * (size_t)mm, count, st));
+        HIPCHK(h, trtri_lower(st, A0 + L.oBm, mp, A0 + L.oInvDB, LBinv, mp, T1, mp, mp, count, ss, ss));
+      }
+      HIPCHK(h, gemm_mm(st, 0, 0, LBinv, Linv, R, GEMM_A_LOWER | GEMM_B_LOWER));
+      HIPCHK(h, gemm_mm(st, 1, 0, R, R, Sinv, GEMM_A_UPPER | GEMM_B_LOWER));
+      HIPCHK(h, gemm_mm(st, 0, 0, Bfull, Linv, T2, GEMM_B_LOWER));
+      HIPCHK(h, gemm_mm(st, 1, 0, Linv, T2, T1, GEMM_A_UPPER));
+      // m = L^-T LB^-T c
+      HIPCHK(h, gemm_mm(st, 1, 0, Linv, Linv, Qinv, GEMM_A_UPPER | GEMM_B_LOWER));
+      hipLaunchKernelGGL(copy_row_batch_kernel, dim3((mp + 255) / 256, count), dim3(256), 0, st, (const double*)crow, mvec, mp, ss);
+      HIPCHK(h, trsv_lower(st, A0 + L.oBm, mp, A0 + L.oInvDB, mvec, mp, true, count, ss));
+      HIPCHK(h, trsv_lower(st, A0 + L.oQm, mp, A0 + L.oInvDL, mvec, mp, true, count, ss));
+      hipLaunchKernelGGL(sgpr_combine_kernel, dim3((mp * mp + 255) / 256, count), dim3(256), 0, st, (const double*)Qinv, (const double*)Sinv,
+                         (const double*)T1, (const double*)mvec, mp, W, GQ, ss);
+    }
     HIPCHK(h, launch_gemm(st, 0, 0, mp, np, mp, 1.0, W, mp, A0 + L.oP, np, 0.0, A0 + L.oWP, np, 0, 0, 1, 0, 0, 0, count, ss, ss, ss));
     TraceArgs tp{A0 + L.oZ, h->X.p, nullptr, A0 + L.oWP, np, mvec, A0 + L.oY, 0.0, 0.0, m, n, d, 0.0, 0, partP, A0 + L.oWHP, np, tiles_n};
     tp.cell_par = cpar;
@@ -1074,30 +1108,83 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     tq.b_stride = ss;
     tq.wh_stride = ss;
     HIPCHK(h, launch_trace(st, h->kid, with_form(tq, h), tiles_m * tiles_m, count));
-    hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums, ss, ss);
-    hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width, ss, ss);
-    hipLaunchKernelGGL(dz_kernel, dim3(m * d, count), dim3(256), 0, st, (const double*)(A0 + L.oZ), (const double*)h->X.p,
-                       (const double*)(A0 + L.oWHP), (int64_t)np, (const double*)(A0 + L.oWHQ), (int64_t)mp, (const double*)nullptr, m, n, d,
-                       A0 + L.odZ, ss, cpar);
     HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, A0 + L.oP, np, mvec, 1, 0.0, qvec, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss));
     hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oY), (const double*)qvec, n, A0 + L.oRed + 4, ss,
                        ss);
-    const int nb = mp < 64 ? mp : 64;
-    double* part = A0 + L.oVecs + 2 * mp;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb, count), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, part, ss);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1, count), dim3(64), 0, st, (const double*)part, nb, A0 + L.oRed + 3, ss);
+    if (fused_small) {
+      // (|LB^-1|_F^2 came out of sgpr_small_kernel)
+    } else {
+      const int nb = mp < 64 ? mp : 64;
+      double* part = A0 + L.oVecs + 2 * mp;
+      hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb, count), dim3(256), 0, st, (const double*)LBinv, (int64_t)mp, mp, mp, part, ss);
+      hipLaunchKernelGGL(sum_partials_kernel, dim3(1, count), dim3(64), 0, st, (const double*)part, nb, A0 + L.oRed + 3, ss);
+    }
+    hipLaunchKernelGGL(dz_kernel, dim3(dz_grid(m, d), count), dim3(256), 0, st, (const double*)(A0 + L.oZ), (const double*)h->X.p,
+                       (const double*)(A0 + L.oWHP), (int64_t)np, (const double*)(A0 + L.oWHQ), (int64_t)mp, (const double*)nullptr, m, n, d,
+                       A0 + L.odZ, ss, cpar);
   }
-  // ---- results: reductions, pivot status, trace sums, dZ ----
-  double* hres = h->spin + (size_t)count * CELL_PAR;                // CELL_RES per cell
-  double* hred = hres + (size_t)count * CELL_RES;                   // 8 per cell
-  double* hsum = hred + (size_t)count * 8;                          // 2 * width per cell
-  double* hdz = hsum + (size_t)count * 2 * width;                   // m * d per cell
-  HIPCHK(h, hipMemcpyAsync(hres, h->cellres.p, sizeof(double) * CELL_RES * count, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpy2DAsync(hred, sizeof(double) * 8, A0 + L.oRed, pitch, sizeof(double) * 8, count, hipMemcpyDeviceToHost, st));
-  if (g) {
-    HIPCHK(h, hipMemcpy2DAsync(hsum, sizeof(double) * 2 * width, sums, pitch, sizeof(double) * 2 * width, count, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpy2DAsync(hdz, sizeof(double) * m * d, A0 + L.odZ, pitch, sizeof(double) * m * d, count, hipMemcpyDeviceToHost, st));
+  // ---- results: reductions, pivot status, trace sums, dZ -> pinned memory ----
+  hipLaunchKernelGGL(sgpr_stage_out_kernel, dim3(count), dim3(256), 0, st, (const double*)h->cellres.p, CELL_RES, h->spin + sg.res,
+                     (const double*)(A0 + L.oRed), h->spin + sg.red, want_grad ? (const double*)partP : nullptr, tiles_m * tiles_n,
+                     (const double*)partQ, tiles_m * tiles_m, width, h->spin + sg.sum, want_grad ? (const double*)(A0 + L.odZ) : nullptr, m * d,
+                     h->spin + sg.dz, ss);
+  HIPCHK(h, hipGetLastError());
+  return GPRX_OK;
+}
+
+// elbo_out[c] (NaN if a Cholesky failed), g: count x ntheta constrained-parameter derivatives, gz: count x m x d (host);
+// g / gz may be null (loss only).  status[c]: GPRX_OK / GPRX_ENOTPD.
+int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta* ts, const double* zs, double* elbo_out, double* g, double* gz,
+                         int* status) {
+  const SgprLayout L = sgpr_batch_layout(h);
+  int rc;
+  if ((rc = ensure_sarena(h, count, L))) return rc;
+  const int mp = (int)h->mp, m = (int)h->m, d = h->d;
+  const int width = L.width;
+  hipStream_t st = h->stream;
+  const SgprStage sg = sgpr_stage(h, count, L);
+  double* par = h->spin + sg.par;
+  for (int c = 0; c < count; ++c) {
+    double* row = par + (size_t)c * CELL_PAR;
+    std::memset(row, 0, sizeof(double) * CELL_PAR);
+    row[0] = ts[c].variance;
+    row[1] = ts[c].noise;
+    row[2] = (double)units[c];
+    row[3] = 1.0 / ts[c].noise;
+    for (int k = 0; k < d; ++k) row[CELL_PAR_LS + k] = ts[c].ls[k];
   }
+  std::memcpy(h->spin + sg.z, zs, sizeof(double) * (size_t)count * m * d);
+  static const bool no_graph = getenv("GPRX_NO_GRAPH") != nullptr;  // escape hatch: eager launches
+  const bool want_grad = g != nullptr;
+  bool replayed = false;
+  if (!no_graph && !h->sgraph_off && !h->profiling) {
+    const std::pair<int, int> key(count, want_grad ? 1 : 0);
+    auto it = h->sgraphs.find(key);
+    if (it == h->sgraphs.end()) {
+      hipGraph_t graph = nullptr;
+      HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      rc = sgpr_batch_enqueue(h, count, L, want_grad);
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      hipGraphExec_t exec = nullptr;
+      if (!rc && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (rc || e != hipSuccess || !exec) {
+        (void)hipGetLastError();  // the capture is abandoned; this handle keeps to eager launches from now on
+        h->sgraph_off = true;
+      } else {
+        it = h->sgraphs.emplace(key, exec).first;
+      }
+    }
+    if (it != h->sgraphs.end()) {
+      HIPCHK(h, hipGraphLaunch(it->second, st));
+      replayed = true;
+    }
+  }
+  if (!replayed && (rc = sgpr_batch_enqueue(h, count, L, want_grad))) return rc;
+  const double* hres = h->spin + sg.res;
+  const double* hred = h->spin + sg.red;
+  const double* hsum = h->spin + sg.sum;
+  const double* hdz = h->spin + sg.dz;
   HIPCHK(h, hipStreamSynchronize(st));
   h->factorized = false;  // the single-model state of the handle is untouched but no longer "the last evaluation"
   int first_error = GPRX_OK;
@@ -1266,7 +1353,7 @@ int gprx_destroy(gprx_handle h) {
   if (h->info) hipFree(h->info);
   if (h->pin) hipHostFree(h->pin);
   if (h->gparams) hipFree(h->gparams);
-  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+  drop_graphs(h);
   for (auto& ev : h->ev)
     if (ev) hipEventDestroy(ev);
   h->pstreams.destroy();
@@ -1327,8 +1414,7 @@ int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units) 
   h->have_linv = false;
   std::fill(h->slot_ok.begin(), h->slot_ok.end(), 0);  // resident batch slots were factorised from the old data
   std::fill(h->slot_unit.begin(), h->slot_unit.end(), -1);
-  for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
-  h->graphs.clear();
+  drop_graphs(h);
   h->yy.assign(n_units, 0.0);
   for (int u = 0; u < n_units; ++u) {
     double acc = 0.0;
@@ -2504,6 +2590,7 @@ int gprx_set_tuning(const char* key, int value) {
 int gprx_set_handle_tuning(gprx_handle h, const char* key, int value) {
   if (!h || !key) return fail(h, GPRX_EINVAL, "null argument");
   if (!apply_tuning(h->tune, h->predict_path, key, value)) return fail(h, GPRX_EINVAL, "unknown tuning key or bad value");
+  if (hipSetDevice(h->device) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) drop_graphs(h);  // captured with the old schedule
   return GPRX_OK;
 }
 

@@ -215,16 +215,21 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
   }
 }
 
-// dELBO/dZ of the sparse model, one workgroup per (inducing point i, dimension k):
+// dELBO/dZ of the sparse model:
 //   dZ[i][k] = ( sum_n WHP[i][n] (z_ik - x_nk) + 2 sum_j WHQ[i][j] (z_ik - z_jk) ) / l_k^2
 // with WHP = dELBO/dKuf * v h and WHQ = dELBO/dKuu * v h as stored by trace_kernel.  The differences
 // are formed explicitly: for kernels whose h is singular at r -> 0 (Matern-1/2, "Exponential") the
 // algebraically equal  z rowsum(WH) - WH X  cancels catastrophically on near-coincident points.
+// One workgroup per (DZ_IG inducing points, DZ_DC dimensions): a point's coordinates are loaded once for all of them and
+// a row of WHP once per chunk of dimensions (one workgroup per (i, k) re-read x for every i and WHP for every k: 0.5 GB
+// of L2 traffic and 96 us for 16 cells of M = 50, N = 4096, d = 10).  Per output the operation order is unchanged:
+// thread t accumulates n = t, t + 256, ... with one FMA each, wave sums, the four waves added in order.
+constexpr int DZ_IG = 2, DZ_DC = 16;
 __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, const double* __restrict__ X, const double* __restrict__ WHP,
                                                  int64_t ldp, const double* __restrict__ WHQ, int64_t ldq, const double* __restrict__ ls,
                                                  int m, int n, int d, double* __restrict__ dZ, int64_t cs = 0,
                                                  const double* __restrict__ cell_par = nullptr) {
-  __shared__ double sred[4];
+  __shared__ double sred[4][DZ_IG * DZ_DC];
   if (cell_par) {  // batched: blockIdx.y = cell; Z, WHP, WHQ, dZ live in the cell block, lengthscales in the table
     const int64_t off = (int64_t)blockIdx.y * cs;
     Z += off;
@@ -233,17 +238,59 @@ __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, c
     dZ += off;
     ls = cell_par + (int64_t)blockIdx.y * CELL_PAR + CELL_PAR_LS;
   }
-  const int i = blockIdx.x / d, k = blockIdx.x % d;
-  const double z = Z[(int64_t)i * d + k];
-  double acc = 0.0;
-  for (int c = threadIdx.x; c < n; c += 256) acc = __builtin_fma(WHP[(int64_t)i * ldp + c], z - X[(int64_t)c * d + k], acc);
-  double accq = 0.0;
-  for (int c = threadIdx.x; c < m; c += 256) accq = __builtin_fma(WHQ[(int64_t)i * ldq + c], z - Z[(int64_t)c * d + k], accq);
-  acc = wave_sum(acc + 2.0 * accq);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  const int kchunks = (d + DZ_DC - 1) / DZ_DC;
+  const int i0 = ((int)blockIdx.x / kchunks) * DZ_IG, k0 = ((int)blockIdx.x % kchunks) * DZ_DC;
+  const int ni = min(DZ_IG, m - i0), nk = min(DZ_DC, d - k0);
+  double z[DZ_IG][DZ_DC];  // uniform over the workgroup: scalar registers
+#pragma unroll
+  for (int ii = 0; ii < DZ_IG; ++ii)
+#pragma unroll
+    for (int kk = 0; kk < DZ_DC; ++kk) z[ii][kk] = (ii < ni && kk < nk) ? Z[(int64_t)(i0 + ii) * d + k0 + kk] : 0.0;
+  double acc[DZ_IG][DZ_DC], accq[DZ_IG][DZ_DC];
+#pragma unroll
+  for (int ii = 0; ii < DZ_IG; ++ii)
+#pragma unroll
+    for (int kk = 0; kk < DZ_DC; ++kk) acc[ii][kk] = accq[ii][kk] = 0.0;
+  for (int c = threadIdx.x; c < n; c += 256) {
+    double x[DZ_DC], w[DZ_IG];
+#pragma unroll
+    for (int kk = 0; kk < DZ_DC; ++kk) x[kk] = kk < nk ? X[(int64_t)c * d + k0 + kk] : 0.0;
+#pragma unroll
+    for (int ii = 0; ii < DZ_IG; ++ii) w[ii] = ii < ni ? WHP[(int64_t)(i0 + ii) * ldp + c] : 0.0;
+#pragma unroll
+    for (int ii = 0; ii < DZ_IG; ++ii)
+#pragma unroll
+      for (int kk = 0; kk < DZ_DC; ++kk) acc[ii][kk] = __builtin_fma(w[ii], z[ii][kk] - x[kk], acc[ii][kk]);
+  }
+  for (int c = threadIdx.x; c < m; c += 256) {
+    double x[DZ_DC], w[DZ_IG];
+#pragma unroll
+    for (int kk = 0; kk < DZ_DC; ++kk) x[kk] = kk < nk ? Z[(int64_t)c * d + k0 + kk] : 0.0;
+#pragma unroll
+    for (int ii = 0; ii < DZ_IG; ++ii) w[ii] = ii < ni ? WHQ[(int64_t)(i0 + ii) * ldq + c] : 0.0;
+#pragma unroll
+    for (int ii = 0; ii < DZ_IG; ++ii)
+#pragma unroll
+      for (int kk = 0; kk < DZ_DC; ++kk) accq[ii][kk] = __builtin_fma(w[ii], z[ii][kk] - x[kk], accq[ii][kk]);
+  }
+#pragma unroll
+  for (int ii = 0; ii < DZ_IG; ++ii)
+#pragma unroll
+    for (int kk = 0; kk < DZ_DC; ++kk) {
+      const double a = wave_sum(acc[ii][kk] + 2.0 * accq[ii][kk]);
+      if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][ii * DZ_DC + kk] = a;
+    }
   __syncthreads();
-  if (threadIdx.x == 0) dZ[(int64_t)i * d + k] = (sred[0] + sred[1] + sred[2] + sred[3]) / (ls[k] * ls[k]);
+  const int e = threadIdx.x;
+  if (e < DZ_IG * DZ_DC) {
+    const int ii = e / DZ_DC, kk = e % DZ_DC;
+    if (ii < ni && kk < nk) {
+      const double l = ls[k0 + kk];
+      dZ[(int64_t)(i0 + ii) * d + k0 + kk] = (sred[0][e] + sred[1][e] + sred[2][e] + sred[3][e]) / (l * l);
+    }
+  }
 }
+inline int dz_grid(int m, int d) { return ((m + DZ_IG - 1) / DZ_IG) * ((d + DZ_DC - 1) / DZ_DC); }
 
 // out[e] = sum over workgroups of partial[wg][e]
 __global__ __launch_bounds__(64) void trace_final(const double* __restrict__ partial, int nwg, int width, double* __restrict__ out,
@@ -251,6 +298,21 @@ __global__ __launch_bounds__(64) void trace_final(const double* __restrict__ par
   const int e = blockIdx.x;
   partial += (int64_t)blockIdx.y * partial_stride;  // batched: blockIdx.y = cell, results width (or out_stride) apart
   out += (int64_t)blockIdx.y * (out_stride < 0 ? width : out_stride);
+  double s = 0.0;
+  for (int w = threadIdx.x; w < nwg; w += 64) s += partial[(int64_t)w * width + e];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[e] = s;
+}
+
+// trace_final for two partial blocks in one launch: blockIdx.x < width -> (partial_a, nwg_a) into out[e], else (partial_b, nwg_b)
+// into out[width + e]
+__global__ __launch_bounds__(64) void trace_final2(const double* __restrict__ partial_a, int nwg_a, const double* __restrict__ partial_b, int nwg_b,
+                                                   int width, double* __restrict__ out, int64_t partial_stride, int64_t out_stride) {
+  const bool second = (int)blockIdx.x >= width;
+  const int e = second ? (int)blockIdx.x - width : (int)blockIdx.x;
+  const double* partial = (second ? partial_b : partial_a) + (int64_t)blockIdx.y * partial_stride;
+  const int nwg = second ? nwg_b : nwg_a;
+  out += (int64_t)blockIdx.y * out_stride + (second ? width : 0);
   double s = 0.0;
   for (int w = threadIdx.x; w < nwg; w += 64) s += partial[(int64_t)w * width + e];
   s = wave_sum(s);

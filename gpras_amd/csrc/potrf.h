@@ -325,20 +325,23 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
 constexpr int ROWS_WG = 128;
 constexpr int ROWS_LSTR = NB + 1;  // LDS row stride of the L11 image
 
-template <int P>
-__device__ __forceinline__ void rows_step(d4 (&acc)[2][4], double* __restrict__ sIn, double* __restrict__ sX, const double* __restrict__ sL,
+// RT = 16-row tiles per wave: 2 -> 128 rows per workgroup (half of the threads substitute), 4 -> 256 rows per workgroup
+// (every thread substitutes one row; one L11 image in LDS serves twice the rows).
+template <int P, int RT>
+__device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__ sIn, double* __restrict__ sX, const double* __restrict__ sL,
                                           const double* __restrict__ sRinv, int tid, int wave, int g, int r) {
   constexpr int C0 = 8 * P;
   constexpr int KT = C0 / 16;
   constexpr int HALF = P & 1;
+  constexpr int WROWS = 16 * RT;
   if ((r >> 3) == HALF) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sIn[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)] = acc[rt][KT][q];
+      for (int q = 0; q < 4; ++q) sIn[(WROWS * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)] = acc[rt][KT][q];
   }
   __syncthreads();
-  if (tid < ROWS_WG) {
+  if (tid < 64 * RT) {
     double x[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -353,11 +356,11 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[2][4], double* __restrict__ 
   __syncthreads();
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
-    double fa[2][2], fb[4][2];
+    double fa[RT][2], fb[4][2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -sX[(32 * wave + 16 * rt + r) * PSUB + 4 * ks + g];
+      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -sX[(WROWS * wave + 16 * rt + r) * PSUB + 4 * ks + g];
 #pragma unroll
     for (int kt = KT0; kt < 4; ++kt) {
       const int kk = kt * 16 + r;
@@ -367,46 +370,48 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[2][4], double* __restrict__ 
 #pragma unroll
     for (int kt = KT0; kt < 4; ++kt)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
       }
   }
   if ((r >> 3) == HALF) {  // solved values back into the accumulators (see potrf_panel_kernel): one coalesced store pass at the end
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = sX[(32 * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)];
+      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = sX[(WROWS * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)];
   }
 }
 
 // A21: first row below the diagonal block (rows_below rows, lda); stage: this panel's staged L11 (64 x 64) followed by
-// the 64 reciprocal pivots.  grid = (ceil(rows_below / 128), cells).
-__global__ __launch_bounds__(256, 3) void potrf_rows_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
-                                                            const double* __restrict__ stage, int64_t cs) {
-  __shared__ __attribute__((aligned(16))) double sIn[ROWS_WG * PSUB];
-  __shared__ __attribute__((aligned(16))) double sX[ROWS_WG * PSUB];
+// the 64 reciprocal pivots.  grid = (ceil(rows_below / (64 RT)), cells).
+template <int RT, int OCC>
+__global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
+                                                              const double* __restrict__ stage, int64_t cs) {
+  constexpr int WG_ROWS = 64 * RT, WROWS = 16 * RT;
+  __shared__ __attribute__((aligned(16))) double sIn[WG_ROWS * PSUB];
+  __shared__ __attribute__((aligned(16))) double sX[WG_ROWS * PSUB];
   __shared__ __attribute__((aligned(16))) double sL[NB * ROWS_LSTR];
   __shared__ double sRinv[NB];
   A21 += (int64_t)blockIdx.y * cs;
   stage += (int64_t)blockIdx.y * cs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
-  const int row0 = blockIdx.x * ROWS_WG;
+  const int row0 = blockIdx.x * WG_ROWS;
   // own rows -> accumulator layout, every load unconditional (rows past the end re-read row 0 and are masked)
-  d4 acc[2][4];
+  d4 acc[RT][4];
   {
-    const double* rowp[2][4];
-    bool valid[2][4];
+    const double* rowp[RT][4];
+    bool valid[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int idx = row0 + 32 * wave + 16 * rt + g + 4 * q;
+        const int idx = row0 + WROWS * wave + 16 * rt + g + 4 * q;
         valid[rt][q] = idx < rows_below;
         rowp[rt][q] = A21 + (int64_t)(valid[rt][q] ? idx : 0) * lda + r;
       }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -420,26 +425,26 @@ __global__ __launch_bounds__(256, 3) void potrf_rows_kernel(double* __restrict__
     }
     if (tid < NB) sRinv[tid] = stage[NB * NB + tid];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = valid[rt][q] ? acc[rt][kt][q] : 0.0;
   }
   // (the first barrier inside rows_step<0> also publishes sL / sRinv)
-  rows_step<0>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<1>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<2>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<3>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<4>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<5>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<6>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<7>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<0, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<1, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<2, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<3, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<4, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<5, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<6, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<7, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int idx = row0 + 32 * wave + 16 * rt + g + 4 * q;
+      const int idx = row0 + WROWS * wave + 16 * rt + g + 4 * q;
       if (idx < rows_below) {
         double* dst = A21 + (int64_t)idx * lda + r;
 #pragma unroll
@@ -1004,9 +1009,18 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out, prev_stage,
                          prev_dst, prev_pw, cs, info_stride);
       // ... then the rows below it, 128 per workgroup
-      if (rows_below > 0)
-        hipLaunchKernelGGL(potrf_rows_kernel, dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda, lda,
-                           rows_below, (const double*)stage_out, cs);
+      if (rows_below > 0) {
+        static const int rows_variant = getenv("GPRX_ROWS_VARIANT") ? atoi(getenv("GPRX_ROWS_VARIANT")) : 0;
+        if (rows_variant == 1)
+          hipLaunchKernelGGL((potrf_rows_kernel<4, 2>), dim3((rows_below + 255) / 256, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda, lda,
+                             rows_below, (const double*)stage_out, cs);
+        else if (rows_variant == 2)
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 2>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda,
+                             lda, rows_below, (const double*)stage_out, cs);
+        else
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 3>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda,
+                             lda, rows_below, (const double*)stage_out, cs);
+      }
     } else {
       const int own = PanelGeom<2>::kOwnRows;
       const int nchunks = (rows_below + own - 1) / own;

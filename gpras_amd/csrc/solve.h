@@ -122,9 +122,12 @@ inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const
 
 // ---- matrix right-hand side: L X = B (in place), recursive halving onto MFMA GEMMs -------------
 // cells > 1: the same solve for `cells` systems whose L, inv_diag and B are all cs doubles apart
+// src (n == NB only): the right-hand side is read from there instead of B (same leading dimension), B only receives the
+// solution -- saves the copy a caller would make to keep the right-hand side.
 inline hipError_t trsm_lower_left(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* B, int64_t ldb,
-                                  int n, int ncols, int cells = 1, int64_t cs = 0) {
-  if (n == NB) return launch_gemm(st, 0, 0, NB, ncols, NB, 1.0, inv_diag, NB, B, ldb, 0.0, B, ldb, GEMM_A_LOWER, 64, 1, 0, 0, 0, cells, cs, cs, cs);
+                                  int n, int ncols, int cells = 1, int64_t cs = 0, const double* src = nullptr) {
+  if (n == NB)
+    return launch_gemm(st, 0, 0, NB, ncols, NB, 1.0, inv_diag, NB, src ? src : B, ldb, 0.0, B, ldb, GEMM_A_LOWER, 64, 1, 0, 0, 0, cells, cs, cs, cs);
   const int n1 = (n / NB / 2) * NB, n2 = n - n1;
   hipError_t e = trsm_lower_left(st, L, lda, inv_diag, B, ldb, n1, ncols, cells, cs);
   if (e != hipSuccess) return e;
