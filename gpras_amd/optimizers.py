@@ -197,12 +197,75 @@ def _evaluate_many(models, want_grad: bool = True, stats: dict | None = None):
     return losses, packed
 
 
+class _PackedBatch:
+    """The hyperparameters of many models as rows of 2-D arrays for the duration of one batched driver: the per-model
+    ``theta()`` / ``set_vector`` / ``_pack_grad`` calls of a step (three small numpy concatenations per model: 0.5 ms per step
+    at 50 modes, as much as the device's share) become three column-indexed array operations.  Same numbers: the columns are
+    only moved.  ``write_back`` leaves the models as ``set_vector`` would have."""
+
+    def __init__(self, models):
+        from .model import TRAIN_LENGTHSCALE, TRAIN_NOISE, TRAIN_VARIANCE, TRAIN_Z
+
+        self.models = models
+        self.eng = models[0].backend
+        self.mask = models[0].mask
+        nt = self.eng.n_theta
+        self.units = np.array([m.unit for m in models], dtype=np.int32)
+        self.thetas = np.stack([m.theta() for m in models])
+        self.zs = None if models[0].Z is None else np.stack([m.Z for m in models]).astype(np.float64)
+        zsize = 0 if self.zs is None else self.zs[0].size
+        theta_cols, x_cols, grad_cols, pos = [], [], [], 0
+        self.z_cols = None
+        if self.mask & TRAIN_Z:
+            self.z_cols = slice(0, zsize)
+            grad_cols += list(range(nt, nt + zsize))
+            pos = zsize
+        if self.mask & TRAIN_LENGTHSCALE:
+            for k in range(1, nt - 1):
+                theta_cols.append(k); x_cols.append(pos); grad_cols.append(k); pos += 1
+        if self.mask & TRAIN_VARIANCE:
+            theta_cols.append(0); x_cols.append(pos); grad_cols.append(0); pos += 1
+        if self.mask & TRAIN_NOISE:
+            theta_cols.append(nt - 1); x_cols.append(pos); grad_cols.append(nt - 1); pos += 1
+        self.theta_cols, self.x_cols, self.grad_cols = np.array(theta_cols, dtype=int), np.array(x_cols, dtype=int), np.array(grad_cols, dtype=int)
+
+    @staticmethod
+    def usable(models) -> bool:
+        m0 = models[0]
+        return (len(models) > 1 and hasattr(m0.backend, "objective_batch") and all(m.backend is m0.backend and m.mask == m0.mask for m in models)
+                and all((m.Z is None) == (m0.Z is None) for m in models))
+
+    def assign(self, rows, x_rows):
+        """``set_vector(x)`` for the given models, in the arrays."""
+        if self.z_cols is not None:
+            self.zs[rows] = x_rows[:, self.z_cols].reshape((len(rows),) + self.zs.shape[1:])
+        if self.theta_cols.size:
+            self.thetas[np.ix_(rows, self.theta_cols)] = x_rows[:, self.x_cols]
+
+    def evaluate(self, rows, stats=None):
+        if stats is not None:
+            stats["batches"] = stats.get("batches", 0) + 1
+        units = self.units[rows]
+        losses, grads, ok = self.eng.objective_batch(units, self.thetas[rows], self.mask, want_grad=True, zs=None if self.zs is None else self.zs[rows])
+        if not ok.all():
+            raise np.linalg.LinAlgError(f"kernel matrix not positive definite for unit(s) {[int(units[i]) for i in np.flatnonzero(~ok)]}")
+        for i in rows:
+            self.models[i].n_evals += 1
+        return losses, grads[:, self.grad_cols]
+
+    def write_back(self, x):
+        for m, row in zip(self.models, x):
+            m.set_vector(row)
+
+
 def _optimize_adam_many(models, max_iter: int, stats: dict | None = None) -> None:
     """``_optimize_adam`` for every model, one batched evaluation per step (same constants, same early stop per model)."""
     lr, beta1, beta2, eps = 1e-3, 0.9, 0.999, 1e-7
     x = np.stack([m.get_vector() for m in models])
     if x.shape[1] == 0:
         return
+    if _PackedBatch.usable(models):
+        return _adam_packed(_PackedBatch(models), x, int(max_iter), stats)
     mom = np.zeros_like(x)
     v = np.zeros_like(x)
     best = np.full(len(models), np.inf)
@@ -230,6 +293,39 @@ def _optimize_adam_many(models, max_iter: int, stats: dict | None = None) -> Non
                 count[i] += 1
                 if count[i] > patience:
                     active[i] = False
+
+
+def _adam_packed(batch: "_PackedBatch", x, max_iter: int, stats) -> None:
+    """The loop of ``_optimize_adam_many`` on packed arrays: per element the same operations in the same order."""
+    lr, beta1, beta2, eps = 1e-3, 0.9, 0.999, 1e-7
+    n = x.shape[0]
+    mom = np.zeros_like(x)
+    v = np.zeros_like(x)
+    best = np.full(n, np.inf)
+    count = np.zeros(n, dtype=int)
+    active = np.ones(n, dtype=bool)
+    tol = 10e-6
+    patience = 50
+    try:
+        for t in range(1, max_iter + 1):
+            idx = np.flatnonzero(active)
+            if idx.size == 0:
+                break
+            losses, g = batch.evaluate(idx, stats)
+            mom[idx] = beta1 * mom[idx] + (1.0 - beta1) * g
+            v[idx] = beta2 * v[idx] + (1.0 - beta2) * g * g
+            alpha = lr * np.sqrt(1.0 - beta2**t) / (1.0 - beta1**t)
+            x[idx] = x[idx] - alpha * mom[idx] / (np.sqrt(v[idx]) + eps)
+            batch.assign(idx, x[idx])
+            with np.errstate(invalid="ignore", divide="ignore"):
+                improved = ((best[idx] - losses) / np.abs(losses)) > tol
+            best[idx[improved]] = losses[improved]
+            count[idx[improved]] = 0
+            stale = idx[~improved]
+            count[stale] += 1
+            active[stale[count[stale] > patience]] = False
+    finally:
+        batch.write_back(x)
 
 
 def _optimize_two_stage_many(models, max_iter: int = 100, stats: dict | None = None) -> None:
