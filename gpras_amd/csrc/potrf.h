@@ -327,9 +327,17 @@ constexpr int ROWS_LSTR = NB + 1;  // LDS row stride of the L11 image
 
 // RT = 16-row tiles per wave: 2 -> 128 rows per workgroup (half of the threads substitute), 4 -> 256 rows per workgroup
 // (every thread substitutes one row; one L11 image in LDS serves twice the rows).
-template <int P, int RT>
+// WAVE_LOCAL: a wave substitutes its OWN 16 RT rows (lanes < 16 RT), so nothing crosses waves and the two workgroup barriers
+// of a sub-panel become wave-scope fences: the four waves of a workgroup drift apart and overlap their phases.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int P, int RT, bool SCALAR_L = false, bool WAVE_LOCAL = false>
 __device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__ sIn, double* __restrict__ sX, const double* __restrict__ sL,
-                                          const double* __restrict__ sRinv, int tid, int wave, int g, int r) {
+                                          const double* __restrict__ sRinv, int tid, int wave, int g, int r,
+                                          const double* __restrict__ gstage = nullptr) {
   constexpr int C0 = 8 * P;
   constexpr int KT = C0 / 16;
   constexpr int HALF = P & 1;
@@ -340,20 +348,26 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__
 #pragma unroll
       for (int q = 0; q < 4; ++q) sIn[(WROWS * wave + 16 * rt + g + 4 * q) * PSUB + (r & 7)] = acc[rt][KT][q];
   }
-  __syncthreads();
-  if (tid < 64 * RT) {
+  if constexpr (WAVE_LOCAL) wave_sync_lds(); else __syncthreads();
+  const int srow = WAVE_LOCAL ? WROWS * wave + (tid & 63) : tid;
+  if (WAVE_LOCAL ? (tid & 63) < WROWS : tid < 64 * RT) {
     double x[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      double t = sIn[tid * PSUB + k];
+      double t = sIn[srow * PSUB + k];
 #pragma unroll
-      for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], sL[(C0 + k) * ROWS_LSTR + C0 + m], t);
-      x[k] = t * sRinv[C0 + k];
+      for (int m = 0; m < k; ++m) {
+        // SCALAR_L: the 8 x 8 diagonal sub-block and the pivots through scalar loads from the staged block (uniform addresses:
+        // s_load into SGPRs that v_fma_f64 takes directly) instead of 44 LDS broadcast reads per row and sub-panel
+        const double lkm = SCALAR_L ? gstage[(C0 + k) * NB + C0 + m] : sL[(C0 + k) * ROWS_LSTR + C0 + m];
+        t = __builtin_fma(-x[m], lkm, t);
+      }
+      x[k] = t * (SCALAR_L ? gstage[NB * NB + C0 + k] : sRinv[C0 + k]);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sX[tid * PSUB + k] = x[k];
+    for (int k = 0; k < 8; ++k) sX[srow * PSUB + k] = x[k];
   }
-  __syncthreads();
+  if constexpr (WAVE_LOCAL) wave_sync_lds(); else __syncthreads();
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
     double fa[RT][2], fb[4][2];
@@ -365,7 +379,8 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__
     for (int kt = KT0; kt < 4; ++kt) {
       const int kk = kt * 16 + r;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fb[kt][ks] = (kk >= C0 + 8) ? sL[kk * ROWS_LSTR + C0 + 4 * ks + g] : 0.0;
+      for (int ks = 0; ks < 2; ++ks)
+        fb[kt][ks] = (kk >= C0 + 8) ? (SCALAR_L && sL == nullptr ? gstage[kk * NB + C0 + 4 * ks + g] : sL[kk * ROWS_LSTR + C0 + 4 * ks + g]) : 0.0;
     }
 #pragma unroll
     for (int kt = KT0; kt < 4; ++kt)
@@ -385,14 +400,15 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__
 
 // A21: first row below the diagonal block (rows_below rows, lda); stage: this panel's staged L11 (64 x 64) followed by
 // the 64 reciprocal pivots.  grid = (ceil(rows_below / (64 RT)), cells).
-template <int RT, int OCC>
+template <int RT, int OCC, bool SCALAR_L = false, bool NO_LDS_L = false, bool WAVE_LOCAL = false>
 __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
                                                               const double* __restrict__ stage, int64_t cs) {
   constexpr int WG_ROWS = 64 * RT, WROWS = 16 * RT;
   __shared__ __attribute__((aligned(16))) double sIn[WG_ROWS * PSUB];
   __shared__ __attribute__((aligned(16))) double sX[WG_ROWS * PSUB];
-  __shared__ __attribute__((aligned(16))) double sL[NB * ROWS_LSTR];
+  __shared__ __attribute__((aligned(16))) double sLbuf[NO_LDS_L ? 1 : NB * ROWS_LSTR];
   __shared__ double sRinv[NB];
+  double* sL = NO_LDS_L ? nullptr : sLbuf;
   A21 += (int64_t)blockIdx.y * cs;
   stage += (int64_t)blockIdx.y * cs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
@@ -417,13 +433,15 @@ __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = rowp[rt][q][kt * 16];
     // L11 image and the reciprocal pivots (staged by the diagonal workgroup of this panel)
-    for (int e = tid; e < NB * NB / 2; e += 256) {
-      const int row = e / (NB / 2), cc = e % (NB / 2);
-      const d2 v = *reinterpret_cast<const d2*>(stage + row * NB + 2 * cc);
-      sL[row * ROWS_LSTR + 2 * cc] = v.x;
-      sL[row * ROWS_LSTR + 2 * cc + 1] = v.y;
+    if constexpr (!NO_LDS_L) {
+      for (int e = tid; e < NB * NB / 2; e += 256) {
+        const int row = e / (NB / 2), cc = e % (NB / 2);
+        const d2 v = *reinterpret_cast<const d2*>(stage + row * NB + 2 * cc);
+        sL[row * ROWS_LSTR + 2 * cc] = v.x;
+        sL[row * ROWS_LSTR + 2 * cc + 1] = v.y;
+      }
+      if (tid < NB) sRinv[tid] = stage[NB * NB + tid];
     }
-    if (tid < NB) sRinv[tid] = stage[NB * NB + tid];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -432,14 +450,14 @@ __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict
         for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = valid[rt][q] ? acc[rt][kt][q] : 0.0;
   }
   // (the first barrier inside rows_step<0> also publishes sL / sRinv)
-  rows_step<0, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<1, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<2, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<3, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<4, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<5, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<6, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
-  rows_step<7, RT>(acc, sIn, sX, sL, sRinv, tid, wave, g, r);
+  rows_step<0, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<1, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<2, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<3, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<4, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<5, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<6, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  rows_step<7, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -1010,16 +1028,20 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
                          prev_dst, prev_pw, cs, info_stride);
       // ... then the rows below it, 128 per workgroup
       if (rows_below > 0) {
-        static const int rows_variant = getenv("GPRX_ROWS_VARIANT") ? atoi(getenv("GPRX_ROWS_VARIANT")) : 0;
-        if (rows_variant == 1)
-          hipLaunchKernelGGL((potrf_rows_kernel<4, 2>), dim3((rows_below + 255) / 256, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda, lda,
-                             rows_below, (const double*)stage_out, cs);
-        else if (rows_variant == 2)
-          hipLaunchKernelGGL((potrf_rows_kernel<2, 2>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda,
-                             lda, rows_below, (const double*)stage_out, cs);
+        // default: no L11 image in LDS (the 8 x 8 diagonal sub-blocks and pivots through scalar loads, the MFMA operands straight
+        // from the staged block, L1 / L2 resident): 18 KB of LDS and 116 VGPRs, four workgroups per CU instead of three.  The
+        // kernel is bound by its own dependent chain (8 sub-panels x (LDS round trip, 44-FMA substitution, MFMA update)), not by
+        // bandwidth (3.3 TB/s) -- rows in flight per CU are what counts: -0.5 ms per 128-cell step at N = 4096.  Measured without
+        // effect: 256-row workgroups, scalar loads alone.  With nothing shared in LDS a wave substitutes its own 32 rows and the
+        // workgroup barriers become wave-scope fences (another -0.3 ms).  GPRX_ROWS_LDS=1 restores the LDS image and the barriers
+        // (same values either way).
+        static const bool rows_lds = getenv("GPRX_ROWS_LDS") != nullptr;
+        if (rows_lds)
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 3, false, false>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
+                             Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs);
         else
-          hipLaunchKernelGGL((potrf_rows_kernel<2, 3>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st, Acc + (int64_t)NB * lda,
-                             lda, rows_below, (const double*)stage_out, cs);
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 4, true, true, true>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
+                             Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs);
       }
     } else {
       const int own = PanelGeom<2>::kOwnRows;
