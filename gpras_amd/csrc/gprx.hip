@@ -1007,14 +1007,13 @@ int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_
   kp.out_stride = ss;
   kp.a_stride = ss;
   kp.diag_const = 1;
-  HIPCHK(h, launch_kmat(st, h->kid, with_form(kp, h), count));
   KmatArgs kq{A0 + L.oZ, A0 + L.oZ, nullptr, A0 + L.oQm, mp, m, m, d, mp, mp, 0.0, JITTER, 2, 1.0, nullptr, 0};
   kq.cell_par = cpar;
   kq.out_stride = ss;
   kq.a_stride = ss;
   kq.b_stride = ss;
   kq.diag_const = 1;
-  HIPCHK(h, launch_kmat(st, h->kid, with_form(kq, h), count));
+  HIPCHK(h, launch_kmat_pair(st, h->kid, with_form(kp, h), with_form(kq, h), count));  // Kuf and Kuu in one launch
   int* info0 = reinterpret_cast<int*>(h->cellres.p + 2);
   HIPCHK(h, potrf_lower(st, A0 + L.oQm, mp, mp, 0, A0 + L.oInvDL, info0, A0 + L.oStage, nullptr, nullptr, count, ss, 2 * CELL_RES, &h->tune));
   const bool one_block = mp == NB;  // M <= 64 (the reference's default is 50): every M x M matrix is one 64 x 64 tile
@@ -1099,7 +1098,6 @@ int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_
     tp.a_stride = ss;
     tp.wh_stride = ss;
     tp.scale_inv_noise = 1;
-    HIPCHK(h, launch_trace(st, h->kid, with_form(tp, h), tiles_m * tiles_n, count));
     TraceArgs tq{A0 + L.oZ, A0 + L.oZ, nullptr, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, 0.0, 0, partQ, A0 + L.oWHQ, mp, tiles_m};
     tq.cell_par = cpar;
     tq.w_stride = ss;
@@ -1107,7 +1105,7 @@ int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_
     tq.a_stride = ss;
     tq.b_stride = ss;
     tq.wh_stride = ss;
-    HIPCHK(h, launch_trace(st, h->kid, with_form(tq, h), tiles_m * tiles_m, count));
+    HIPCHK(h, launch_trace_pair(st, h->kid, with_form(tp, h), tiles_m * tiles_n, with_form(tq, h), tiles_m * tiles_m, count));
     HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, A0 + L.oP, np, mvec, 1, 0.0, qvec, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss));
     hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oY), (const double*)qvec, n, A0 + L.oRed + 4, ss,
                        ss);

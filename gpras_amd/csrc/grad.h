@@ -43,10 +43,7 @@ struct TraceArgs {
 // Output per workgroup (deterministic two-stage reduction, no atomics):
 //   partial[wg][0] = sum w g          partial[wg][1] = sum_{i == j} w      partial[wg][2 + k] = -sum w v h ds_k^2 / l_k
 template <int KID, int FORM = 0>
-__global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
-  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
-  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
-  __shared__ double sRed[4][KM_DC + 2];
+__device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_DC], double (*sBt)[KM_T], double (*sRed)[KM_DC + 2]) {
   if (p.cell_par) {
     const double* par = p.cell_par + (int64_t)blockIdx.y * CELL_PAR;
     p.ls = par + CELL_PAR_LS;
@@ -62,8 +59,8 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
     if (p.wh_out) p.wh_out += (int64_t)blockIdx.y * p.wh_stride;
     if (p.scale_inv_noise) p.w_scale = p.uv_scale = par[3];
   }
-  const int ti = blockIdx.x / p.tiles_n, tj = blockIdx.x % p.tiles_n;
-  double* out = p.partial + (int64_t)blockIdx.x * (2 + p.d);
+  const int ti = bx / p.tiles_n, tj = bx % p.tiles_n;
+  double* out = p.partial + (int64_t)bx * (2 + p.d);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (p.sym && tj > ti) {
     for (int e = tid; e < 2 + p.d; e += 256) out[e] = 0.0;
@@ -215,6 +212,25 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
   }
 }
 
+template <int KID, int FORM = 0>
+__global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
+  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  __shared__ double sRed[4][KM_DC + 2];
+  trace_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt, sRed);
+}
+// Two contractions in one launch (the sparse model's Kuf and Kuu terms): workgroups [0, first) take p, the rest q.
+template <int KID, int FORM = 0>
+__global__ __launch_bounds__(256) void trace_pair_kernel(TraceArgs p, TraceArgs q, int first) {
+  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  __shared__ double sRed[4][KM_DC + 2];
+  if ((int)blockIdx.x < first)
+    trace_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt, sRed);
+  else
+    trace_body<KID, FORM>(q, (int)blockIdx.x - first, sA, sBt, sRed);
+}
+
 // dELBO/dZ of the sparse model:
 //   dZ[i][k] = ( sum_n WHP[i][n] (z_ik - x_nk) + 2 sum_j WHQ[i][j] (z_ik - z_jk) ) / l_k^2
 // with WHP = dELBO/dKuf * v h and WHQ = dELBO/dKuu * v h as stored by trace_kernel.  The differences
@@ -327,6 +343,28 @@ inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid, i
       hipLaunchKernelGGL((trace_kernel<K_, 1>), g, b, 0, st, p);              \
     else                                                                      \
       hipLaunchKernelGGL((trace_kernel<K_, 0>), g, b, 0, st, p);              \
+    break;
+  switch (kid) {
+    GPRX_TRACE_CASE(0)
+    GPRX_TRACE_CASE(1)
+    GPRX_TRACE_CASE(2)
+    GPRX_TRACE_CASE(3)
+    GPRX_TRACE_CASE(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef GPRX_TRACE_CASE
+  return hipGetLastError();
+}
+
+inline hipError_t launch_trace_pair(hipStream_t st, int kid, TraceArgs p, int grid_p, TraceArgs q, int grid_q, int cells = 1) {
+  if (p.form != q.form) return hipErrorInvalidValue;
+  dim3 g(grid_p + grid_q, cells), b(256);
+#define GPRX_TRACE_CASE(K_)                                                                \
+  case K_:                                                                                 \
+    if (p.form)                                                                            \
+      hipLaunchKernelGGL((trace_pair_kernel<K_, 1>), g, b, 0, st, p, q, grid_p);           \
+    else                                                                                   \
+      hipLaunchKernelGGL((trace_pair_kernel<K_, 0>), g, b, 0, st, p, q, grid_p);           \
     break;
   switch (kid) {
     GPRX_TRACE_CASE(0)

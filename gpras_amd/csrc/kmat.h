@@ -111,10 +111,8 @@ constexpr int CELL_PAR_LS = 8;
 // FORM (compile time: the default difference form keeps the registers and code of the kernel it always was -- as a run-time
 // branch the expanded form's extra accumulators cost the default path 50 %: 2.8 -> 4.2 ms for 128 cells of N = 4096)
 template <int KID, int FORM = 0>
-__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
-  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
-  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
-  const int ti = blockIdx.x / p.tiles_n, tj = blockIdx.x % p.tiles_n;
+__device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC], double (*sBt)[KM_T]) {
+  const int ti = bx / p.tiles_n, tj = bx % p.tiles_n;
   if (p.mode == 1 && tj > ti) return;
   const int i0 = ti * KM_T, j0 = tj * KM_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,6 +216,24 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   }
 }
 
+template <int KID, int FORM = 0>
+__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
+  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  kmat_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt);
+}
+// Two builds in one launch (the sparse model's Kuf and Kuu): workgroups [0, first) take p, the rest q.  A dependent launch
+// costs ~10 us on this part whatever it computes.
+template <int KID, int FORM = 0>
+__global__ __launch_bounds__(256) void kmat_pair_kernel(KmatArgs p, KmatArgs q, int first) {
+  __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  if ((int)blockIdx.x < first)
+    kmat_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt);
+  else
+    kmat_body<KID, FORM>(q, (int)blockIdx.x - first, sA, sBt);
+}
+
 inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p, int batch = 1) {
   const int tiles_m = (p.n1p + KM_T - 1) / KM_T;
   p.tiles_n = (p.n2p + KM_T - 1) / KM_T;
@@ -229,6 +245,31 @@ inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p, int batch = 1
       hipLaunchKernelGGL((kmat_kernel<K_, 1>), grid, block, 0, st, p);              \
     else                                                                            \
       hipLaunchKernelGGL((kmat_kernel<K_, 0>), grid, block, 0, st, p);              \
+    break;
+  switch (kid) {
+    GPRX_KMAT_CASE(0)
+    GPRX_KMAT_CASE(1)
+    GPRX_KMAT_CASE(2)
+    GPRX_KMAT_CASE(3)
+    GPRX_KMAT_CASE(4)
+    default: return hipErrorInvalidValue;
+  }
+#undef GPRX_KMAT_CASE
+  return hipGetLastError();
+}
+
+inline hipError_t launch_kmat_pair(hipStream_t st, int kid, KmatArgs p, KmatArgs q, int batch = 1) {
+  p.tiles_n = (p.n2p + KM_T - 1) / KM_T;
+  q.tiles_n = (q.n2p + KM_T - 1) / KM_T;
+  const int np_ = ((p.n1p + KM_T - 1) / KM_T) * p.tiles_n, nq = ((q.n1p + KM_T - 1) / KM_T) * q.tiles_n;
+  if (np_ == 0 || nq == 0 || p.form != q.form) return hipErrorInvalidValue;
+  dim3 grid(np_ + nq, batch), block(256);
+#define GPRX_KMAT_CASE(K_)                                                                       \
+  case K_:                                                                                       \
+    if (p.form)                                                                                  \
+      hipLaunchKernelGGL((kmat_pair_kernel<K_, 1>), grid, block, 0, st, p, q, np_);              \
+    else                                                                                         \
+      hipLaunchKernelGGL((kmat_pair_kernel<K_, 0>), grid, block, 0, st, p, q, np_);              \
     break;
   switch (kid) {
     GPRX_KMAT_CASE(0)

@@ -11,7 +11,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last evaluation: take the final 60 kernels, print name, duration, gap to previous end
-tail = rows[-23:]
+tail = rows[-20:]
 prev = None
 for r in tail:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
