@@ -1,5 +1,5 @@
 """Batched exact fits at size N with `cells` cells per launch sequence: timing loop for rocprofv3 runs (development aid).
-argv: N cells [steps]"""
+argv: N cells [steps] [key=value tuning ...]"""
 import ctypes as C, sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -10,6 +10,9 @@ from gpras_amd.synth import make_regression
 lib = _lib.load()
 n, cells = int(sys.argv[1]), int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for kv in sys.argv[4:]:  # tuning: key=value
+    k, v = kv.split("=")
+    check(lib.gprx_set_tuning(k.encode(), int(v)))
 x, y, _ = make_regression(n, 8, n_outputs=cells, n_test=0, config=2, unit=500)
 h = C.c_void_p()
 check(lib.gprx_create(0, n, 8, 0, 0, 0, C.byref(h)))

@@ -1,9 +1,14 @@
 #!/bin/bash
 set -e
-for v in 0 1 0 1; do
-  if [ $v = 1 ]; then export GPRX_ROWS_WAVE=1; else unset GPRX_ROWS_WAVE; fi
-  echo "== GPRX_ROWS_WAVE=$v"
-  timeout -k 10 120 python tools/batch_prof.py 4096 128 10
-  timeout -k 10 120 python tools/batch_prof.py 1024 512 10
+for w in 1024 512 2048 1024; do
+  echo "== outer_block=$w"
+  timeout -k 10 120 python tools/batch_prof.py 4096 128 10 outer_block=$w
 done
-GPRX_ROWS_WAVE=1 timeout -k 10 300 python -m pytest tests/test_gpu_blocks.py tests/test_gpu_exact.py -x -q 2>&1 | tail -3
+for w in 1024 512 256; do
+  echo "== N=1024 outer_block=$w"
+  timeout -k 10 120 python tools/batch_prof.py 1024 512 10 outer_block=$w
+done
+for w in 1024 2048 512; do
+  echo "== N=2048 outer_block=$w"
+  timeout -k 10 120 python tools/batch_prof.py 2048 256 10 outer_block=$w
+done
