@@ -218,3 +218,46 @@ def test_batched_sparse_predict_equals_single_calls_and_oracle(lib, kernel, n, d
             np.testing.assert_allclose(variances[c] - lat_v[c], par[c][2], rtol=1e-9)
     finally:
         lib.gprx_destroy(h)
+
+
+def test_sparse_batch_failed_cell_is_isolated_and_leaves_no_trace(lib):
+    """One cell of a batched sparse evaluation whose Kuu is numerically singular (variance 1e12, lengthscale 1e6: every entry of
+    Kuu rounds to v, the 1e-6 jitter drowns): that cell reports NaN / GPRX_ENOTPD, the others equal their single calls bit for
+    bit, and the NEXT evaluation on the same handle (captured graph, reused cell blocks) is clean -- NaN left in a cell block
+    must not leak into the following call."""
+    import ctypes as C
+
+    from gpras_amd import _lib
+    from gpras_amd._lib import check, ptr
+    from oracle import kernels as okn
+
+    n, d, m, cells = 600, 4, 40, 3
+    x, y, _ = make_regression(n, d, n_outputs=3, n_test=0, config=14, unit=77)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, m, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 3), h)
+    try:
+        rng = np.random.default_rng(4)
+        units = np.arange(cells, dtype=np.int32)
+        good = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, 3)))
+        zs = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] for _ in range(cells)]))
+        singles = []
+        for c in range(cells):
+            s, g = C.c_double(), np.zeros(3 + m * d)
+            check(lib.gprx_objective(h, c, ptr(np.ascontiguousarray(good[c])), ptr(np.ascontiguousarray(zs[c])), 15, C.byref(s), ptr(g)), h)
+            singles.append((s.value, g))
+        bad = good.copy()
+        bad[1] = [1e12, 1e6, 0.0]
+        for rep in range(2):  # twice: the second failing call replays the captured graph
+            losses, grads = np.zeros(cells), np.zeros((cells, 3 + m * d))
+            rc = lib.gprx_objective_batch(h, cells, ptr(units), ptr(bad), ptr(zs), 15, ptr(losses), ptr(grads))
+            assert rc == _lib.GPRX_ENOTPD
+            assert np.isnan(losses[1])
+            for c in (0, 2):
+                assert losses[c] == singles[c][0] and np.array_equal(grads[c], singles[c][1])
+            losses, grads = np.zeros(cells), np.zeros((cells, 3 + m * d))
+            check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(good), ptr(zs), 15, ptr(losses), ptr(grads)), h)
+            for c in range(cells):
+                assert losses[c] == singles[c][0] and np.array_equal(grads[c], singles[c][1])
+    finally:
+        lib.gprx_destroy(h)

@@ -1,12 +1,26 @@
 #!/bin/bash
-# kmat kernel at N = 1024 / 2048 / 4096 with different cell counts: time per tile
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for cfg in "1024 512" "1024 128" "2048 256" "4096 128" "512 2048"; do
-  set -- $cfg
-  rm -rf gpurun_out/kmat_trace
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kmat_trace -o s -- python3 tools/batch_prof.py $1 $2 3 > gpurun_out/kmat_trace.log 2>&1
-  f=$(find gpurun_out/kmat_trace -name "*kernel_stats.csv" | head -1)
-  echo "N=$1 cells=$2: $(tail -1 gpurun_out/kmat_trace.log)"
-  grep -E "kmat_kernel|potrf_rows|trsv_bwd|potrf_panel" $f | cut -d, -f1-4 | cut -c1-140
-done
+rm -rf gpurun_out/kmat_trace
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kmat_trace -o s -- python3 tools/batch_prof.py 1024 512 5 > gpurun_out/kmat_trace.log 2>&1
+f=$(find gpurun_out/kmat_trace -name "*kernel_stats.csv" | head -1)
+cp $f gpurun_out/n1024_stats.csv
+python3 - <<'PY'
+import csv
+rows=list(csv.DictReader(open('gpurun_out/n1024_stats.csv')))
+tot=sum(int(r['TotalDurationNs']) for r in rows)
+print('total ms per step', tot/1e6/7)
+for r in rows[:10]:
+    print(r['Name'][:70], r['Calls'], round(int(r['TotalDurationNs'])/1e3/7,1), 'us/step', round(float(r['AverageNs'])/1e3,1), r['Percentage'])
+PY
+t=$(find gpurun_out/kmat_trace -name "*kernel_trace.csv" | head -1)
+python3 - "$t" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = max(i for i, r in enumerate(rows) if "kmat_kernel" in r["Kernel_Name"])
+for r in rows[idx:]:
+    name = r["Kernel_Name"].replace("void gprx::", "").replace("gprx::", "").split("(")[0]
+    if "gemm" in name:
+        print(f"{name[:40]:40s} grid {int(r['Grid_Size_X'])//256:6d} dur {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:8.1f} us")
+PY
 rm -rf gpurun_out/kmat_trace
