@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from gpras_amd.gpr import GPRAS
 from gpras_amd.synth import make_regression
 cells = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-n, d, m = 4096, 10, 50
+n, d, m = 4096, 10, (int(sys.argv[3]) if len(sys.argv) > 3 else 50)
 x, y, _ = make_regression(n, d, n_outputs=cells, n_test=0, config=6, unit=1)
 g = GPRAS("RBF")
 g._init_models(x.astype(np.float64), y.astype(np.float64), m, "grid")
