@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void copy_block_kernel(const double* __restric
   flush_staged_block(stage + (int64_t)blockIdx.x * cs, dst + (int64_t)blockIdx.x * cs, lda, pw, threadIdx.x);
 }
 
-template <int RT, int OCC>
+template <int RT, int OCC, bool FUSE_K64 = false>
 __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
                                                           double* __restrict__ inv_diag, int* __restrict__ info, int col0,
                                                           double* __restrict__ stage_out, const double* __restrict__ prev_stage,
@@ -260,12 +260,66 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
         rowp[rt][q] = A + mrow * lda + c.r;
         valid[rt][q] = ok;
       }
+    d4 upd[FUSE_K64 ? RT : 1][4];
+    if constexpr (FUSE_K64) {
+      // The K = 64 update that the schedule would launch between the previous panel and this one (these 64 columns, every
+      // row from the diagonal block down, by the 64 columns left of them), applied here to the rows this workgroup holds: one
+      // dependent launch less per odd panel (~9 us of a lone matrix's chain).  Operation for operation what gemm_f64 does
+      // (accumulators from zero, stages of 16 along k, instruction j of a stage takes k = k0 + 4 g + j; C + (-1) * sum with one
+      // rounding), so the factor is the same bit for bit as with the separate launch (batched cells keep that launch).
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) upd[rt][kt] = d4{0.0, 0.0, 0.0, 0.0};
+      const double* arow[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int wrow = WROWS * c.wave + 16 * rt + c.r;  // A operand: lane (g, r) supplies row r of the tile, k = 4 g + j
+        const int idx = (int)blockIdx.x * PANEL_ROWS + (wrow - NB);
+        const bool diag = wrow < NB;
+        const bool ok = diag || (!last && idx < rows_below);
+        arow[rt] = A + (diag ? wrow : (ok ? NB + idx : 0)) * lda - NB + 4 * c.g;
+      }
+      const double* brow = A + (int64_t)c.r * lda - NB + 4 * c.g;  // B operand: rows of the diagonal block (row 16 kt + r)
+#pragma unroll
+      for (int k0 = 0; k0 < NB; k0 += 16) {
+        double fa[RT][4], fb[4][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const d2 lo = *reinterpret_cast<const d2*>(arow[rt] + k0), hi = *reinterpret_cast<const d2*>(arow[rt] + k0 + 2);
+          fa[rt][0] = lo.x; fa[rt][1] = lo.y; fa[rt][2] = hi.x; fa[rt][3] = hi.y;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const double* bp = brow + (int64_t)(16 * kt) * lda + k0;
+          const d2 lo = *reinterpret_cast<const d2*>(bp), hi = *reinterpret_cast<const d2*>(bp + 2);
+          fb[kt][0] = lo.x; fb[kt][1] = lo.y; fb[kt][2] = hi.x; fb[kt][3] = hi.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) upd[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][j], fb[kt][j], upd[rt][kt], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = rowp[rt][q][kt * 16];
+    if constexpr (FUSE_K64) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double v = -1.0 * upd[rt][kt][q];
+            acc[rt][kt][q] = __builtin_fma(1.0, acc[rt][kt][q], v);
+          }
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -998,7 +1052,15 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   // a fused launch would fill the chip with redundant factorisations; bit-identical either way
   const bool split_panel = tune.split_panel ? tune.split_panel > 0 : batch >= 24;  // measured at N = 4096: -2 % at 16 cells per launch, +5 % at 32
   // one panel: factor the diagonal block at column c and solve every row below it
-  auto panel = [&](int c, int pw) {
+  // fuse: the K = 64 update of these 64 columns by the 64 columns left of them happens inside the panel kernel (lone
+  // matrices: one dependent launch less); only where the separate launch would be the general NT kernel (same arithmetic)
+  static const bool fuse_ok = [] {
+    const char* a = getenv("GPRX_K64_GEMM");
+    const char* b = getenv("GPRX_GEMM_DMA");
+    const char* c = getenv("GPRX_FUSE_K64");
+    return !(a && atoi(a) == 0) && !(b && atoi(b) == 0) && !(c && atoi(c) == 0);
+  }();
+  auto panel = [&](int c, int pw, bool fuse = false) {
     const int rows_below = total_rows - c - pw;
     double* Acc = A + (int64_t)c * lda + c;
     if (prof) {
@@ -1049,6 +1111,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       if (tune.panel_occ == 3)
         hipLaunchKernelGGL((potrf_panel_kernel<2, 3>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
                            col_base + c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
+      else if (fuse)
+        hipLaunchKernelGGL((potrf_panel_kernel<2, 2, true>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
+                           col_base + c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
       else
         hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(nchunks + 1, batch), dim3(256), 0, st, Acc, lda, rows_below, nchunks, invd, info,
                            col_base + c, stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
@@ -1082,6 +1147,10 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     }
     const int h = ((w / NB + 1) / 2) * NB;
     self(self, c0, h);
+    if (h == NB && w - h == NB && pwidth != PW && !split_panel && fuse_ok && tune.panel_rows != 256 && tune.panel_occ != 3) {
+      panel(c0 + h, NB, true);  // the K = 64 update of the right panel rides in its own kernel
+      return;
+    }
     inblock_update(c0, h, c0 + h, w - h);
     self(self, c0 + h, w - h);
   };
