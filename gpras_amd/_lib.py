@@ -56,6 +56,7 @@ PROTOTYPES = {
     "gprx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "gprx_last_profile": (C.c_int, [_vp, _dp]),
     "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "gprx_adam_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "gprx_comm_unique_id": (C.c_int, [_vp]),
     "gprx_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "gprx_comm_destroy": (C.c_int, [_vp]),

@@ -1514,6 +1514,74 @@ int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const
   return first_error;
 }
 
+int gprx_adam_batch(gprx_handle h, int count, const int* units, double* theta, double* z, int mask, int max_iter, int* n_evals, int* batches) {
+#pragma clang fp contract(off)
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (count <= 0 || !units || !theta || !n_evals || max_iter < 0) return fail(h, GPRX_EINVAL, "null argument");
+  if (h->m != 0 && !z) return fail(h, GPRX_EINVAL, "z (inducing inputs) is null for a sparse model");
+  const int nt = h->ntheta;
+  const int64_t nz = h->m * h->d, gw = nt + nz;
+  if (batches) *batches = 0;
+  for (int i = 0; i < count; ++i) n_evals[i] = 0;
+  // trainable elements of a cell's gradient row [d theta | d Z] (theta: [variance, lengthscales..., noise])
+  std::vector<char> train((size_t)gw, 0);
+  train[0] = (mask & GPRX_TRAIN_VARIANCE) != 0;
+  for (int k = 1; k < nt - 1; ++k) train[k] = (mask & GPRX_TRAIN_LENGTHSCALE) != 0;
+  train[nt - 1] = (mask & GPRX_TRAIN_NOISE) != 0;
+  for (int64_t e = 0; e < nz; ++e) train[nt + e] = (mask & GPRX_TRAIN_Z) != 0;
+  bool any = false;
+  for (char t : train) any = any || t;
+  if (!any) return GPRX_OK;  // nothing trainable: no step can change anything (optimizers._optimize_adam returns at once)
+  const double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, eps = 1e-7, tol = 10e-6;
+  const int patience = 50;
+  std::vector<double> mom((size_t)count * gw, 0.0), vel((size_t)count * gw, 0.0), best(count, std::numeric_limits<double>::infinity());
+  std::vector<int> stale(count, 0), active(count);
+  for (int i = 0; i < count; ++i) active[i] = i;
+  std::vector<int> a_units(count);
+  std::vector<double> a_theta((size_t)count * nt), a_z((size_t)count * nz), losses(count), grads((size_t)count * gw);
+  for (int t = 1; t <= max_iter && !active.empty(); ++t) {
+    const int na = (int)active.size();
+    for (int j = 0; j < na; ++j) {
+      const int i = active[j];
+      a_units[j] = units[i];
+      std::memcpy(&a_theta[(size_t)j * nt], theta + (size_t)i * nt, sizeof(double) * nt);
+      if (nz) std::memcpy(&a_z[(size_t)j * nz], z + (size_t)i * nz, sizeof(double) * nz);
+    }
+    rc = gprx_objective_batch(h, na, a_units.data(), a_theta.data(), nz ? a_z.data() : nullptr, mask, losses.data(), grads.data());
+    if (batches) ++*batches;
+    for (int j = 0; j < na; ++j) ++n_evals[active[j]];
+    if (rc) return rc;  // (GPRX_ENOTPD included: the reference's optimiser dies with the exception of that evaluation)
+    const double alpha = lr * std::sqrt(1.0 - std::pow(beta2, (double)t)) / (1.0 - std::pow(beta1, (double)t));
+    std::vector<int> next;
+    next.reserve(na);
+    for (int j = 0; j < na; ++j) {
+      const int i = active[j];
+      double* mo = &mom[(size_t)i * gw];
+      double* ve = &vel[(size_t)i * gw];
+      const double* g = &grads[(size_t)j * gw];
+      for (int64_t e = 0; e < gw; ++e) {
+        if (!train[e]) continue;
+        const double ge = g[e];
+        mo[e] = beta1 * mo[e] + (1.0 - beta1) * ge;
+        ve[e] = beta2 * ve[e] + ((1.0 - beta2) * ge) * ge;
+        double* x = e < nt ? theta + (size_t)i * nt + e : z + (size_t)i * nz + (e - nt);
+        *x = *x - (alpha * mo[e]) / (std::sqrt(ve[e]) + eps);
+      }
+      const double loss = losses[j];
+      if (((best[i] - loss) / std::fabs(loss)) > tol) {
+        best[i] = loss;
+        stale[i] = 0;
+        next.push_back(i);
+      } else if (++stale[i] <= patience) {
+        next.push_back(i);
+      }
+    }
+    active.swap(next);
+  }
+  return GPRX_OK;
+}
+
 int gprx_factorize_batch(gprx_handle h, int count, const int* units, const double* thetas, int mask, double* losses, int* status) {
   int rc;
   if ((rc = check_handle(h))) return rc;

@@ -148,6 +148,33 @@ class Engine:
             check(rc, self._h)
         return losses, grads, np.isfinite(losses)
 
+    @_locked
+    def adam_batch(self, units, thetas, mask: int, max_iter: int, zs=None):
+        """``_optimize_adam`` (gpr.py:147-173) for ``len(units)`` cells in lock step inside the library (``gprx_adam_batch``): one
+        batched evaluation per step, the update on the C side.  Returns ``(thetas, zs, n_evals, batches)`` -- the optimiser's
+        variables after the run (copies), evaluations per cell, batched evaluations made.  Raises as ``objective_batch`` does when
+        a cell stops being positive definite (the arrays of that step are attached to the exception as ``.state``)."""
+        units = np.ascontiguousarray(units, dtype=np.int32)
+        thetas = np.array(thetas, dtype=np.float64, order="C")
+        if thetas.shape != (units.size, self.n_theta):
+            raise ValueError(f"thetas must be ({units.size}, {self.n_theta})")
+        zp = None
+        if self.m != 0:
+            zs = np.array(zs, dtype=np.float64, order="C")
+            if zs.shape != (units.size, self.m, self.d):
+                raise ValueError(f"zs must be ({units.size}, {self.m}, {self.d})")
+            zp = ptr(zs)
+        n_evals = np.zeros(units.size, dtype=np.int32)
+        batches = C.c_int()
+        rc = self._lib.gprx_adam_batch(self._h, units.size, ptr(units), ptr(thetas), zp, int(mask), int(max_iter), ptr(n_evals), C.byref(batches))
+        if rc != _lib.GPRX_OK:
+            try:
+                check(rc, self._h)
+            except Exception as exc:  # noqa: BLE001
+                exc.state = (thetas, zs, n_evals, batches.value)
+                raise
+        return thetas, (zs if self.m != 0 else None), n_evals, batches.value
+
     def max_cells(self, want_grad: bool = False, reserve: float = 0.15) -> int:
         """How many cells of a batched call fit into the free device memory (``gprx_cell_bytes`` against ``gprx_mem_info``,
         keeping ``reserve`` of the total free for predict tiles and other handles); at least 1."""

@@ -265,7 +265,10 @@ def _optimize_adam_many(models, max_iter: int, stats: dict | None = None) -> Non
     if x.shape[1] == 0:
         return
     if _PackedBatch.usable(models):
-        return _adam_packed(_PackedBatch(models), x, int(max_iter), stats)
+        batch = _PackedBatch(models)
+        if hasattr(batch.eng, "adam_batch"):
+            return _adam_in_library(batch, x, int(max_iter), stats)
+        return _adam_packed(batch, x, int(max_iter), stats)
     mom = np.zeros_like(x)
     v = np.zeros_like(x)
     best = np.full(len(models), np.inf)
@@ -293,6 +296,40 @@ def _optimize_adam_many(models, max_iter: int, stats: dict | None = None) -> Non
                 count[i] += 1
                 if count[i] > patience:
                     active[i] = False
+
+
+def _adam_in_library(batch: "_PackedBatch", x, max_iter: int, stats) -> None:
+    """The same loop inside ``libgprx.so`` (``gprx_adam_batch``): nothing of a step runs in Python.  Same numbers as
+    ``_adam_packed`` (the C loop restates the NumPy expressions operation by operation; tests hold both against the serial driver)."""
+    from .model import TRAIN_Z
+
+    def store(thetas, zs, n_evals, batches):
+        if stats is not None:
+            stats["batches"] = stats.get("batches", 0) + int(batches)
+        for m, k in zip(batch.models, n_evals):
+            m.n_evals += int(k)
+        batch.thetas[:] = thetas
+        if zs is not None and batch.zs is not None:
+            batch.zs[:] = zs
+        # back into the packed vector, then into the models exactly as set_vector would
+        if batch.z_cols is not None and (batch.mask & TRAIN_Z):
+            x[:, batch.z_cols] = batch.zs.reshape(len(batch.models), -1)
+        if batch.theta_cols.size:
+            x[:, batch.x_cols] = batch.thetas[:, batch.theta_cols]
+        batch.write_back(x)
+
+    try:
+        out = batch.eng.adam_batch(batch.units, batch.thetas, batch.mask, max_iter, zs=batch.zs)
+    except MemoryError:
+        # the batch does not fit in device memory: the Python loop splits its evaluations (Engine.objective_batch); the library
+        # ran out on the first evaluation, before any update
+        return _adam_packed(batch, x, max_iter, stats)
+    except Exception as exc:  # noqa: BLE001
+        state = getattr(exc, "state", None)
+        if state is not None:
+            store(*state)  # the models keep the variables of the step that failed, as in the Python loop
+        raise
+    store(*out)
 
 
 def _adam_packed(batch: "_PackedBatch", x, max_iter: int, stats) -> None:

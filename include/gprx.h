@@ -246,6 +246,17 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
 int gprx_predict_batch_dev(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs_dev, int64_t ns,
                            double* means_dev, double* vars_dev, int include_noise);
 
+/* The reference's Adam driver (gpr.py:147-173: tf.keras.optimizers.Adam() defaults, at most max_iter steps, early stop once the
+ * relative improvement of the loss stayed <= 1e-5 for more than 50 consecutive steps) for `count` cells in lock step: every step
+ * is ONE batched evaluation (gprx_objective_batch) of the cells still running, the update happens here on the host side of the
+ * library -- no per-step round trip through the caller's language.  theta (count, n_theta) and z (count, m, d; NULL for exact
+ * models) are the optimiser's variables, updated in place (elements outside `mask` stay as they are); n_evals[i] receives the
+ * number of evaluations cell i took part in; batches (optional) the number of batched evaluations.  The arithmetic per element
+ * is that of the NumPy statement of the update (one rounding per operation, no contraction): the result equals
+ * gpras_amd.optimizers._optimize_adam on each cell bit for bit.  A cell whose matrix stops being positive definite ends the
+ * call with GPRX_ENOTPD (gpr.py: the exception leaves the optimiser); theta / z hold the state of that step. */
+int gprx_adam_batch(gprx_handle h, int count, const int* units, double* theta, double* z, int mask, int max_iter, int* n_evals, int* batches);
+
 /* ---- EOF (PCA) projection either side of the GP path: SURVEY.md section 8(f) row N1 ------------------- */
 /* One projector = the fitted state of a reference PreProcessor (gpras/preprocess.py:868-927): `dry` (n_cells bytes, 1 =
  * always-dry cell, may be NULL = none), `elevations` (n_cells, needed for depth mode and for filling dry cells in wse mode),

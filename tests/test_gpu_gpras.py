@@ -227,3 +227,39 @@ def test_sparse_predict_is_batched_and_equals_the_per_mode_loop():
     ref.fit(x, y, 24, "kmeans", "adam", max_iter=4)
     rmean, rvar = ref.predict(xs)
     assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean)) and np.max(np.abs(var - rvar) / rvar) <= 1e-8
+
+
+@pytest.mark.parametrize("n_inducing", [None, 16])
+def test_adam_inside_the_library_equals_the_python_loops(n_inducing):
+    """gprx_adam_batch (the lock-step Adam driver inside libgprx.so) against the packed Python loop and against the serial
+    per-model driver: same variables bit for bit and the same number of evaluations per model -- including models that stop
+    early (they start at an L-BFGS optimum, so the loss cannot improve by 1e-5 for 50 steps) beside models that keep going."""
+    from gpras_amd import optimizers
+
+    x, y = make_hydrograph_features(260, 3, n_outputs=5, config=1, unit=11)
+
+    def prepared():
+        g = GPRAS("Matern52")
+        g.fit(x, y, n_inducing, "grid", "L-BFGS-B", max_iter=40, lockstep=False)
+        for m in g.models[3:]:  # two models are pushed away from the optimum: they keep improving
+            m.set_vector(m.get_vector() + 0.3)
+        for m in g.models:
+            m.n_evals = 0
+            m.set_all_trainable(True)
+        return g
+
+    a, b, c = prepared(), prepared(), prepared()
+    assert hasattr(a.engine, "adam_batch")
+    optimizers._optimize_adam_many(a.models, 90)  # library loop
+    batch = optimizers._PackedBatch(b.models)
+    optimizers._adam_packed(batch, np.stack([m.get_vector() for m in b.models]), 90, None)  # Python loop, batched evaluations
+    for m in c.models:
+        optimizers._optimize_adam(m, 90)  # serial driver
+    evals = [m.n_evals for m in a.models]
+    assert evals == [m.n_evals for m in b.models] == [m.n_evals for m in c.models]
+    assert max(evals) == 90
+    if n_inducing is None:
+        assert min(evals) < 90  # both kinds of model are present (the sparse models' 40 L-BFGS iterations do not end at an optimum)
+    for ma, mb, mc in zip(a.models, b.models, c.models):
+        va, vb, vc = ma.get_vector(), mb.get_vector(), mc.get_vector()
+        assert np.array_equal(va, vb) and np.array_equal(va, vc)
