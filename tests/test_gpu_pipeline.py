@@ -76,6 +76,23 @@ def test_fields_equal_host_chain(lib, hp, n_inducing):
     np.testing.assert_array_equal(got_truth, want_truth)
 
 
+def test_fields_equal_host_chain_at_a_production_shape(lib):
+    """10 sparse modes, 3 000 test timesteps, 30 011 cells (ragged against every tile size): the (modes, T*) block, its transpose,
+    the reconstruction and the depth conversion over 90 M field values -- still equal to the host chain bit for bit."""
+    from gpras_amd.pipeline import DevicePipeline
+
+    rng = np.random.default_rng(41)
+    gpr, proj, x_test, truth_df, elev = _setup("depth", 24, rng, n=700, d=6, k=10, cells=30011, t_star=3000)
+    pipe = DevicePipeline(gpr, proj)
+    fields = pipe.predict_fields(x_test)
+    pred, conf = fields.to_host()
+    fields.close()
+    _, want_pred, want_conf = _host_chain(gpr, proj, x_test, truth_df.values.copy(), elev, "depth")
+    np.testing.assert_array_equal(pred, want_pred)
+    np.testing.assert_array_equal(conf, want_conf)
+    assert np.isfinite(pred).all() and (pred >= 0).all() and (conf >= 0).all()
+
+
 @pytest.mark.parametrize("hp", ["wse", "velocity"])
 def test_metric_summary_equals_host_chain(lib, tmp_path, hp):
     from gpras_amd.metrics import export_metric_summary
