@@ -145,7 +145,7 @@ int gprx_last_timings(gprx_handle h, double* ms4);
  * events on the launch stream (this perturbs the run slightly: keep it off inside timed regions).
  * gprx_last_profile: out8 = [main GEMM kernel gemm_f64_kernel<0,1,64,64,0> (bulk trailing updates and in-block updates
  *                           with K > 128) total ms, launches, algorithmic flops (all cells of a batch), panel kernel
- *                           total ms, launches, short-K in-block updates (K = 64 syrk_k64_kernel, K = 128 GEMM with C
+ *                           total ms, launches, short-K in-block updates (K = 64 / 128: GEMM with C
  *                           prefetch) total ms, launches, algorithmic flops] of the last exact factorisation(s). */
 int gprx_set_profiling(gprx_handle h, int enabled);
 int gprx_last_profile(gprx_handle h, double* out8);
@@ -157,7 +157,7 @@ int gprx_last_profile(gprx_handle h, double* out8);
  * With count > 1 (and d <= 64) every stage runs once for all cells, the cell index in every launch's grid: exact models
  * -- kernel build, Cholesky, solves, L^-1, K^-1, the trace pass (as gprx_factorize_batch) --, and sparse models -- Kuf,
  * Kuu, both Cholesky factorisations, A, B (split-K), c, the M x M products of the gradient, both trace passes, dZ: the
- * ~45 launches of one evaluation serve all cells.  The values are bit-identical to gprx_objective on each cell.  A cell
+ * ~20 launches of one evaluation (M <= 64; more for larger M) serve all cells.  The values are bit-identical to gprx_objective on each cell.  A cell
  * whose matrix is not positive definite gets NaN loss and gradient and the call returns GPRX_ENOTPD after finishing the
  * others. */
 int gprx_objective_batch(gprx_handle h, int count, const int* units, const double* theta, const double* z, int mask,
