@@ -470,6 +470,45 @@ def main():
             proj.close()
             for b in (dx, dz, dfull, dvfull, drow, dcell, darg):
                 b.free()
+            # the tail of production/analysis/pipeline.py (:256-288) resident in HBM (gpras_amd.pipeline) against the same steps through
+            # host arrays: 10 sparse modes, 500 test timesteps, 50 000 cells
+            from gpras_amd.pipeline import DevicePipeline
+            from gpras_amd.preprocess import EOFProjector as _Proj
+
+            prng = np.random.default_rng(77)
+            pk, pcells, pts = 10, 50_000, 500
+            px, py, pxt = make_regression(N_TRAIN, 10, n_outputs=pk, n_test=pts, config=6, unit=3)
+            pg = GPRAS("RBF", device=device)
+            pg.fit(px, py, 50, "grid", "adam", max_iter=3)
+            pdry = np.zeros(pcells, dtype=bool)
+            pdry[::97] = True
+            pwet = int(pcells - pdry.sum())
+            pelev = prng.uniform(0.0, 2.0, size=pcells)
+            pproj = _Proj(pdry, pelev, prng.normal(size=pwet) + 1.5, prng.uniform(0.5, 1.5, size=pwet), prng.normal(size=(pk, pwet)) / np.sqrt(pk),
+                          prng.normal(size=pk), prng.uniform(0.5, 2.0, size=pk), hydraulic_parameter="wse", device=device)
+            pipe = DevicePipeline(pg, pproj)
+            th, td = [], []
+            for rep in range(3):
+                t1 = time.perf_counter()
+                mp_, vp_ = pg.predict(pxt)
+                yp, yv = pproj.reverse_transform(mp_, vp_)
+                dp = yp - pelev
+                dp[dp < 0] = 0
+                cf = np.sqrt(yv)
+                th.append(time.perf_counter() - t1)
+                t1 = time.perf_counter()
+                fields = pipe.predict_fields(pxt)
+                td.append(time.perf_counter() - t1)
+                if rep == 2:
+                    got_p, got_c = fields.to_host()
+                fields.close()
+            extra["device_pipeline"] = {
+                "shape": {"modes": pk, "test_timesteps": pts, "cells": pcells, "n_train": N_TRAIN, "n_inducing": 50},
+                "predict_reverse_depth_fields_ms_host_chain": 1e3 * min(th[1:]),
+                "predict_reverse_depth_fields_ms_device_resident": 1e3 * min(td[1:]),
+                "fields_equal_host_chain_bitwise": bool(np.array_equal(got_p, dp) and np.array_equal(got_c, cf)),
+            }
+            pproj.close()
             result["extra"] = extra
         except Exception as exc:  # noqa: BLE001
             import traceback
