@@ -204,6 +204,15 @@ class GPRAS:
                 part = idx[lo : lo + chunk]
                 units = [self.models[i].unit for i in part]
                 thetas = np.stack([self.models[i].theta() for i in part])
+                if hasattr(eng, "predict_batch"):
+                    # one call: batched factorisations, L^-1 of every cell by batched launches, x uploaded once (gprx_predict_batch)
+                    try:
+                        mean, var = eng.predict_batch(units, thetas, x)
+                    except np.linalg.LinAlgError as exc:
+                        raise RuntimeError(f"kernel matrix not positive definite for one of the modes {part}: {exc}") from exc
+                    for row, i in enumerate(part):
+                        means[:, i], variances[:, i] = mean[row], var[row]
+                    continue
                 _, ok = eng.factorize_batch(units, thetas, 0)
                 if not ok.all():
                     bad = [part[k] for k in np.flatnonzero(~ok)]

@@ -60,15 +60,11 @@ def test_fields_equal_host_chain(lib, hp, n_inducing):
     pred, conf = fields.to_host()
     fields.close()
     _, want_pred, want_conf = _host_chain(gpr, proj, x_test, truth_df.values.copy(), elev, hp)
-    if n_inducing is not None:
-        # sparse models: the same batched kernels with the same chunking on both sides, and the field kernels restate the numpy
-        # expressions operation by operation
-        np.testing.assert_array_equal(pred, want_pred)
-        np.testing.assert_array_equal(conf, want_conf)
-    else:
-        # exact models: GPRAS.predict goes through the per-slot gprx_predict, the device chain through gprx_predict_batch_dev
-        np.testing.assert_allclose(pred, want_pred, rtol=1e-11, atol=1e-11)
-        np.testing.assert_allclose(conf, want_conf, rtol=1e-9, atol=1e-12)
+    # sparse and exact models alike: the same batched kernels with the same chunking on both sides (GPRAS.predict goes through
+    # gprx_predict_batch, the device chain through gprx_predict_batch_dev), and the field kernels restate the numpy expressions
+    # operation by operation
+    np.testing.assert_array_equal(pred, want_pred)
+    np.testing.assert_array_equal(conf, want_conf)
     truth_dev = pipe.truth_depth_dev(truth_df.values)
     got_truth = truth_dev.to_array(truth_df.shape)
     truth_dev.free()
