@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -150,6 +151,36 @@ int& predict_path_tuning() {
   return v;
 }
 
+// The legacy (NULL) stream is never used.  A legacy-stream call (hipMemcpy, hipMemset, a launch on stream 0, hipDeviceSynchronize)
+// from one host thread is refused while ANOTHER thread captures a graph ("operation would make the legacy stream depend on a
+// capturing blocking stream") and invalidates that capture -- in every capture mode of this runtime.  Synchronous copies and
+// the handle-less entry points go through one non-blocking utility stream per device instead.
+hipStream_t util_stream() {
+  static std::mutex m;
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = streams.find(dev);
+  if (it != streams.end()) return it->second;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  streams.emplace(dev, st);
+  return st;
+}
+hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipStream_t st = util_stream();
+  if (!st) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+hipError_t memset_sync(void* dst, int value, size_t bytes) {
+  hipStream_t st = util_stream();
+  if (!st) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 int ensure(gprx_handle h, Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return GPRX_OK;
   if (b.p && !b.borrowed) HIPCHK(h, hipFree(b.p));
@@ -165,7 +196,7 @@ int ensure_zeroed(gprx_handle h, Buf& b, size_t bytes) {
   if (b.bytes >= bytes) return GPRX_OK;
   int rc = ensure(h, b, bytes);
   if (rc) return rc;
-  HIPCHK(h, hipMemset(b.p, 0, bytes));
+  HIPCHK(h, hipMemsetAsync(b.p, 0, bytes, h->stream));
   return GPRX_OK;
 }
 
@@ -314,6 +345,12 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   return GPRX_OK;
 }
 
+// one stream capture at a time in the process (two concurrent thread-local captures on different handles disturbed each other)
+std::mutex& capture_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 // Throughput mode (gprx_factorize_many with several cells): the ~250 launches of one single-stream fit are
 // captured once per (handle, unit) into a hipGraph and replayed; only the pinned parameter block changes.
 // Measured on MI355X with 16 cells of N = 4096 in flight: 784 fits/s eager, 800 fits/s replayed -- the limit is
@@ -328,8 +365,9 @@ int exact_factorize_replay(gprx_handle h, int unit, const Theta& t) {
     std::memcpy(h->pin, t.ls.data(), sizeof(double) * h->d);
     h->pin[74] = t.variance;
     h->pin[75] = t.noise;
+    std::lock_guard<std::mutex> lock(capture_mutex());  // (captures are serialised over the process, see sgpr_objective_batch)
     hipGraph_t graph = nullptr;
-    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
     const int rc = exact_factorize_enqueue(h, unit, t, false, true);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) {
@@ -437,7 +475,8 @@ __global__ void copy_row_batch_kernel(const double* src, double* dst, int n, int
 void drop_graphs(gprx_handle h) {
   for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
   h->graphs.clear();
-  for (auto& kv : h->sgraphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : h->sgraphs)
+    if (kv.second) hipGraphExecDestroy(kv.second);
   h->sgraphs.clear();
 }
 
@@ -951,7 +990,7 @@ int ensure_sarena(gprx_handle h, int slots, const SgprLayout& L) {
   h->sarena_slots = 0;
   int rc;
   if ((rc = ensure(h, h->sarena, sizeof(double) * (size_t)L.ss * slots))) return rc;
-  HIPCHK(h, hipMemset(h->sarena.p, 0, sizeof(double) * (size_t)L.ss * slots));  // padding of every matrix stays zero
+  HIPCHK(h, hipMemsetAsync(h->sarena.p, 0, sizeof(double) * (size_t)L.ss * slots, h->stream));  // padding of every matrix stays zero
   if ((rc = ensure(h, h->cellpar, sizeof(double) * CELL_PAR * slots))) return rc;
   if ((rc = ensure(h, h->cellres, sizeof(double) * CELL_RES * slots))) return rc;
   const size_t need = (size_t)slots * (CELL_PAR + CELL_RES + 8 + 2 * L.width + 2 * h->m * h->d);
@@ -1159,21 +1198,37 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     const std::pair<int, int> key(count, want_grad ? 1 : 0);
     auto it = h->sgraphs.find(key);
     if (it == h->sgraphs.end()) {
+      // first evaluation of this shape: eager (every kernel's code object gets loaded outside a capture); the capture happens
+      // on the second one
+      h->sgraphs.emplace(key, nullptr);
+    } else if (it->second == nullptr) {
+      // Relaxed capture mode: another host thread may call a legacy-stream API (hipMemset / hipMemcpy of another handle's set-up)
+      // while this capture runs; in the global and thread-local modes the runtime refuses that call ("operation would make the
+      // legacy stream depend on a capturing blocking stream") AND invalidates this capture.  The handle's streams are
+      // non-blocking, so no implicit dependency on the legacy stream exists that the capture could miss.  Captures are
+      // serialised over the process as well; one that fails anyway is abandoned and the handle stays on eager launches.
+      std::lock_guard<std::mutex> lock(capture_mutex());
       hipGraph_t graph = nullptr;
-      HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      rc = sgpr_batch_enqueue(h, count, L, want_grad);
-      hipError_t e = hipStreamEndCapture(st, &graph);
       hipGraphExec_t exec = nullptr;
-      if (!rc && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+      if (e == hipSuccess) {
+        const int crc = sgpr_batch_enqueue(h, count, L, want_grad);
+        e = hipStreamEndCapture(st, &graph);
+        if (!crc && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (crc) e = hipErrorUnknown;
+      }
       if (graph) hipGraphDestroy(graph);
-      if (rc || e != hipSuccess || !exec) {
-        (void)hipGetLastError();  // the capture is abandoned; this handle keeps to eager launches from now on
+      if (e != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        h->err.clear();
         h->sgraph_off = true;
+        h->sgraphs.erase(it);
       } else {
-        it = h->sgraphs.emplace(key, exec).first;
+        it->second = exec;
       }
     }
-    if (it != h->sgraphs.end()) {
+    it = h->sgraphs.find(key);
+    if (!h->sgraph_off && it != h->sgraphs.end() && it->second != nullptr) {
       HIPCHK(h, hipGraphLaunch(it->second, st));
       replayed = true;
     }
@@ -1405,8 +1460,8 @@ int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units) 
   std::vector<double> yt((size_t)h->np * n_units, 0.0);
   for (int64_t i = 0; i < h->n; ++i)
     for (int u = 0; u < n_units; ++u) yt[(size_t)u * h->np + i] = y[i * n_units + u];
-  HIPCHK(h, hipMemcpy(h->X.p, x, sizeof(double) * h->n * h->d, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->Y.p, yt.data(), sizeof(double) * yt.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, copy_sync(h->X.p, x, sizeof(double) * h->n * h->d, hipMemcpyHostToDevice));
+  HIPCHK(h, copy_sync(h->Y.p, yt.data(), sizeof(double) * yt.size(), hipMemcpyHostToDevice));
   h->n_units = n_units;
   h->factorized = false;
   h->have_linv = false;
@@ -1986,7 +2041,7 @@ int pensure(gprx_pca_handle p, Buf& b, size_t bytes) {
 int pupload(gprx_pca_handle p, Buf& b, const std::vector<double>& v) {
   int rc = pensure(p, b, sizeof(double) * v.size());
   if (rc) return rc;
-  PCACHK(p, hipMemcpy(b.p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
+  PCACHK(p, copy_sync(b.p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
   return GPRX_OK;
 }
 // device staging per pass of the host-buffer entry points: 1 GiB of x / output (GPRX_PCA_CHUNK_DOUBLES overrides, for tests)
@@ -2198,10 +2253,10 @@ int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const
   HIPCHK(nullptr, hipMalloc((void**)&match_partial, sizeof(unsigned long long) * nwg));
   MetricsArgs a{x_dev, y_dev, conf_dev, rows, cells, v_tol, t_tol, cell_sums_dev, cell_sums_dev + cells, cell_sums_dev + 2 * cells,
                 cell_sums_dev + 3 * cells, cell_sums_dev + 4 * cells, cell_arg_dev, cell_arg_dev + cells, match_partial};
-  hipLaunchKernelGGL(metrics_cells_kernel, dim3(nwg), dim3(256), 0, nullptr, a);
-  hipLaunchKernelGGL(metrics_rows_kernel, dim3((unsigned)rows), dim3(256), 0, nullptr, x_dev, y_dev, conf_dev, cells, row_sums_dev);
+  hipLaunchKernelGGL(metrics_cells_kernel, dim3(nwg), dim3(256), 0, util_stream(), a);
+  hipLaunchKernelGGL(metrics_rows_kernel, dim3((unsigned)rows), dim3(256), 0, util_stream(), x_dev, y_dev, conf_dev, cells, row_sums_dev);
   std::vector<unsigned long long> hm(nwg);
-  hipError_t e = hipMemcpy(hm.data(), match_partial, sizeof(unsigned long long) * nwg, hipMemcpyDeviceToHost);  // synchronises
+  hipError_t e = copy_sync(hm.data(), match_partial, sizeof(unsigned long long) * nwg, hipMemcpyDeviceToHost);  // synchronises
   hipFree(match_partial);
   HIPCHK(nullptr, e);
   unsigned long long total = 0;
@@ -2228,18 +2283,18 @@ int gprx_metrics(int device, const double* x, const double* y, const double* con
   if (e == hipSuccess) e = hipMalloc((void**)&drow, sizeof(double) * rows * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&dcell, sizeof(double) * cells * 5);
   if (e == hipSuccess) e = hipMalloc((void**)&darg, sizeof(int) * cells * 2);
-  if (e == hipSuccess) e = hipMemcpy(dx, x, fb, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dy, y, fb, hipMemcpyHostToDevice);
-  if (e == hipSuccess && conf) e = hipMemcpy(dc, conf, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = copy_sync(dx, x, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = copy_sync(dy, y, fb, hipMemcpyHostToDevice);
+  if (e == hipSuccess && conf) e = copy_sync(dc, conf, fb, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     cleanup();
     return fail(nullptr, e == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string("gprx_metrics staging: ") + hipGetErrorString(e));
   }
   int rc = gprx_metrics_dev(device, dx, dy, dc, rows, cells, t_tol, v_tol, drow, dcell, darg, matches);
   if (rc == GPRX_OK) {
-    e = hipMemcpy(row_sums, drow, sizeof(double) * rows * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(cell_sums, dcell, sizeof(double) * cells * 5, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(cell_arg, darg, sizeof(int) * cells * 2, hipMemcpyDeviceToHost);
+    e = copy_sync(row_sums, drow, sizeof(double) * rows * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_sync(cell_sums, dcell, sizeof(double) * cells * 5, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_sync(cell_arg, darg, sizeof(int) * cells * 2, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(nullptr, GPRX_EHIP, std::string("gprx_metrics copy back: ") + hipGetErrorString(e));
   }
   cleanup();
@@ -2264,9 +2319,9 @@ int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* cen
   if (e == hipSuccess) e = hipMalloc((void**)&dc[1], cb);
   if (e == hipSuccess) e = hipMalloc((void**)&dstat, sizeof(double) * (2 + m));
   if (e == hipSuccess) e = hipMalloc((void**)&dlab, sizeof(int) * n);
-  if (e == hipSuccess) e = hipMemcpy(dx, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dc[0], centers, cb, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(dlab, 0xff, sizeof(int) * n);  // labels_old = -1 (_kmeans_single_lloyd)
+  if (e == hipSuccess) e = copy_sync(dx, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = copy_sync(dc[0], centers, cb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = memset_sync(dlab, 0xff, sizeof(int) * n);  // labels_old = -1 (_kmeans_single_lloyd)
   if (e != hipSuccess) {
     cleanup();
     return fail(nullptr, e == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string("gprx_kmeans_lloyd staging: ") + hipGetErrorString(e));
@@ -2279,10 +2334,10 @@ int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* cen
   for (it = 0; it < max_iter; ++it) {
     // one iteration of lloyd_iter_chunked_dense: labels from the current centres, then the new centres and their shifts
     hipMemsetAsync(dstat, 0, sizeof(double) * 2, nullptr);
-    hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, nullptr, (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3(m), dim3(256), 0, nullptr, (const double*)dx, (int)n, d, (const int*)dlab, (const double*)dc[cur],
+    hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, util_stream(), (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(m), dim3(256), 0, util_stream(), (const double*)dx, (int)n, d, (const int*)dlab, (const double*)dc[cur],
                        dc[cur ^ 1], dstat);
-    e = hipMemcpy(stat.data(), dstat, sizeof(double) * (2 + m), hipMemcpyDeviceToHost);  // synchronises
+    e = copy_sync(stat.data(), dstat, sizeof(double) * (2 + m), hipMemcpyDeviceToHost);  // synchronises
     if (e != hipSuccess) break;
     if (stat[1] != 0.0) {  // scikit-learn relocates empty clusters to far points; the caller falls back to it
       *empty = 1;
@@ -2303,10 +2358,10 @@ int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* cen
   }
   if (e == hipSuccess && !*empty && !strict) {
     // rerun the E-step so that the labels match the final centres
-    hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, nullptr, (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
+    hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, util_stream(), (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
   }
-  if (e == hipSuccess) e = hipMemcpy(centers, dc[cur], cb, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(labels, dlab, sizeof(int) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = copy_sync(centers, dc[cur], cb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = copy_sync(labels, dlab, sizeof(int) * n, hipMemcpyDeviceToHost);
   cleanup();
   HIPCHK(nullptr, e);
   *n_iter = it > max_iter ? max_iter : it;
@@ -2330,10 +2385,10 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
   double* dout = nullptr;
   hipError_t e = hipMalloc((void**)&didx, sizeof(int64_t) * cells);
   if (e == hipSuccess) e = hipMalloc((void**)&dout, sizeof(double) * cells);
-  if (e == hipSuccess) e = hipMemcpy(didx, wrapped.data(), sizeof(int64_t) * cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = copy_sync(didx, wrapped.data(), sizeof(int64_t) * cells, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, nullptr, field_dev, cells, (const int64_t*)didx, dout);
-    e = hipMemcpy(out, dout, sizeof(double) * cells, hipMemcpyDeviceToHost);  // synchronises
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, util_stream(), field_dev, cells, (const int64_t*)didx, dout);
+    e = copy_sync(out, dout, sizeof(double) * cells, hipMemcpyDeviceToHost);  // synchronises
   }
   if (didx) hipFree(didx);
   if (dout) hipFree(dout);
@@ -2549,12 +2604,12 @@ int gprx_dev_free(int device, void* ptr) {
 }
 int gprx_memcpy_h2d(int device, void* dst_dev, const void* src_host, int64_t bytes) {
   HIPCHK(nullptr, hipSetDevice(device));
-  HIPCHK(nullptr, hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+  HIPCHK(nullptr, copy_sync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
   return GPRX_OK;
 }
 int gprx_memcpy_d2h(int device, void* dst_host, const void* src_dev, int64_t bytes) {
   HIPCHK(nullptr, hipSetDevice(device));
-  HIPCHK(nullptr, hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+  HIPCHK(nullptr, copy_sync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
   return GPRX_OK;
 }
 
@@ -2571,11 +2626,11 @@ int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const 
   HIPCHK(nullptr, hipSetDevice(device));
   double* dinv = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dinv, sizeof(double) * d));
-  HIPCHK(nullptr, hipMemcpy(dinv, ls_host, sizeof(double) * d, hipMemcpyHostToDevice));
+  HIPCHK(nullptr, copy_sync(dinv, ls_host, sizeof(double) * d, hipMemcpyHostToDevice));
   KmatArgs ka{a_dev, b_dev, dinv, out_dev, ld, (int)n1, (int)n2, d, (int)n1p, (int)n2p, variance, diag_add, mode, mode ? 1.0 : 0.0, nullptr, 0};
   ka.form = form;
-  hipError_t e = launch_kmat(nullptr, kernel_id, ka);
-  hipError_t e2 = hipDeviceSynchronize();
+  hipError_t e = launch_kmat(util_stream(), kernel_id, ka);
+  hipError_t e2 = hipStreamSynchronize(util_stream());
   hipFree(dinv);
   HIPCHK(nullptr, e);
   HIPCHK(nullptr, e2);
@@ -2589,8 +2644,8 @@ int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, doubl
   if (!((ta == 0 && tb == 1) || (ta == 0 && tb == 0) || (ta == 1 && tb == 0))) return fail(nullptr, GPRX_EINVAL, "unsupported transpose pair");
   if (tile != 0 && tile != 64 && tile != 128) return fail(nullptr, GPRX_EINVAL, "tile must be 0, 64 or 128");
   HIPCHK(nullptr, hipSetDevice(device));
-  HIPCHK(nullptr, launch_gemm(nullptr, ta, tb, (int)m, (int)n, (int)k, alpha, a_dev, lda, b_dev, ldb, beta, c_dev, ldc, flags, tile));
-  HIPCHK(nullptr, hipDeviceSynchronize());
+  HIPCHK(nullptr, launch_gemm(util_stream(), ta, tb, (int)m, (int)n, (int)k, alpha, a_dev, lda, b_dev, ldb, beta, c_dev, ldc, flags, tile));
+  HIPCHK(nullptr, hipStreamSynchronize(util_stream()));
   return GPRX_OK;
 }
 
@@ -2600,7 +2655,7 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   HIPCHK(nullptr, hipSetDevice(device));
   int* dinfo = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dinfo, sizeof(int)));
-  HIPCHK(nullptr, hipMemset(dinfo, 0, sizeof(int)));
+  HIPCHK(nullptr, memset_sync(dinfo, 0, sizeof(int)));
   PotrfStreams ps;
   hipStream_t st = nullptr;
   HIPCHK(nullptr, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -2611,12 +2666,14 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   hipError_t e = use_large_schedule(potrf_tuning(), (int)np)
                      ? potrf_lower_large(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, large, potrf_tuning())
                      : potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
-  hipError_t e2 = hipDeviceSynchronize();
+  hipError_t e2 = hipStreamSynchronize(st);
+  for (hipStream_t side : {ps.aux, large.chain, large.gemm, large.tail})
+    if (side && e2 == hipSuccess) e2 = hipStreamSynchronize(side);
   large.destroy();
   hipFree(dstage);
   ps.destroy();
   hipStreamDestroy(st);
-  hipMemcpy(info_host, dinfo, sizeof(int), hipMemcpyDeviceToHost);
+  copy_sync(info_host, dinfo, sizeof(int), hipMemcpyDeviceToHost);
   hipFree(dinfo);
   HIPCHK(nullptr, e);
   HIPCHK(nullptr, e2);
@@ -2669,11 +2726,12 @@ int gprx_mfma_f64_peak(int device, double* tflops) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 20000, blocks = 256 * 4;
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, out, 100);
-  hipEventRecord(e0, nullptr);
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, out, iters);
-  hipEventRecord(e1, nullptr);
-  hipError_t e = hipDeviceSynchronize();
+  hipStream_t us = util_stream();
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, us, out, 100);
+  hipEventRecord(e0, us);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, us, out, iters);
+  hipEventRecord(e1, us);
+  hipError_t e = hipStreamSynchronize(us);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   hipEventDestroy(e0);

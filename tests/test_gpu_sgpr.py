@@ -261,3 +261,44 @@ def test_sparse_batch_failed_cell_is_isolated_and_leaves_no_trace(lib):
                 assert losses[c] == singles[c][0] and np.array_equal(grads[c], singles[c][1])
     finally:
         lib.gprx_destroy(h)
+
+
+def test_batched_sparse_evaluations_from_two_threads_on_two_handles(lib):
+    """Two host threads, each with its own handle (own stream, own captured graph), evaluate batches at the same time: the
+    captures must not disturb each other (they did -- "operation failed due to a previous error during capture" -- until the
+    library serialised them) and every result equals the single-thread one bit for bit."""
+    import threading
+
+    from gpras_amd.engine import Engine
+
+    n, d, m, cells = 700, 5, 40, 6
+    x, y, _ = make_regression(n, d, n_outputs=cells, n_test=0, config=14, unit=31)
+    rng = np.random.default_rng(12)
+    thetas = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, 3)))
+    zs = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] for _ in range(cells)]))
+    units = np.arange(cells, dtype=np.int32)
+    ref_eng = Engine("Matern32", x, y, m)
+    want = ref_eng.objective_batch(units, thetas, 15, zs=zs)
+    ref_eng.close()
+    engines = [Engine("Matern32", x, y, m) for _ in range(2)]
+    results, errors = [[], []], []
+
+    def run(k):
+        try:
+            for _ in range(6):  # first call eager, second captures, the rest replay
+                results[k].append(engines[k].objective_batch(units, thetas, 15, zs=zs))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engines:
+        e.close()
+    assert not errors, errors
+    for k in range(2):
+        assert len(results[k]) == 6
+        for losses, grads, ok in results[k]:
+            assert ok.all() and np.array_equal(losses, want[0]) and np.array_equal(grads, want[1])
