@@ -2333,7 +2333,9 @@ int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* cen
   *empty = 0;
   for (it = 0; it < max_iter; ++it) {
     // one iteration of lloyd_iter_chunked_dense: labels from the current centres, then the new centres and their shifts
-    hipMemsetAsync(dstat, 0, sizeof(double) * 2, nullptr);
+    // the flags are cleared on the stream the two kernels run on (a non-blocking stream has no ordering with the legacy stream)
+    e = hipMemsetAsync(dstat, 0, sizeof(double) * 2, util_stream());
+    if (e != hipSuccess) break;
     hipLaunchKernelGGL(kmeans_assign_kernel, pgrid, dim3(256), 0, util_stream(), (const double*)dx, (int)n, d, (const double*)dc[cur], m, dlab, dstat);
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(m), dim3(256), 0, util_stream(), (const double*)dx, (int)n, d, (const int*)dlab, (const double*)dc[cur],
                        dc[cur ^ 1], dstat);

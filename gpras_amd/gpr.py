@@ -37,14 +37,23 @@ InductionInitializerType = Literal["kmeans", "grid"]
 
 FILE_FORMAT = modelfile.FILE_FORMAT
 
+# gpflow evaluates r^2 in the expanded form (utilities/ops.py square_distance, behind gpr.py:22,29,298); the kernels whose
+# derivative is singular at r = 0 amplify the difference between the two forms beyond 1e-8, so they default to gpflow's form
+DEFAULT_DISTANCE_FORM = {"Matern12": "expanded", "Exponential": "expanded"}
+
 
 class GPRAS:
     """Gaussian Process Regression for HEC-RAS model upskilling and emulation."""
 
-    def __init__(self, kernel: KernelType, device: int = 0, distance_form: str = "difference") -> None:
-        """``distance_form`` (extension): ``"difference"`` (default) or ``"expanded"`` -- the arithmetic form of the scaled
-        squared distance inside the kernels; ``"expanded"`` is gpflow's literal ``|a|^2 + |b|^2 - 2 a.b``."""
+    def __init__(self, kernel: KernelType, device: int = 0, distance_form: str | None = None) -> None:
+        """``distance_form`` (extension): ``"difference"`` or ``"expanded"`` -- the arithmetic form of the scaled squared
+        distance inside the kernels; ``"expanded"`` is gpflow's literal ``|a|^2 + |b|^2 - 2 a.b``.
+        Default (``None``): ``"expanded"`` for the two kernels that are not differentiable at r = 0 (Matern12, Exponential:
+        there the difference form sits 1.2e-8 / 2.5e-8 from gpflow's arithmetic, outside the 1e-8 this drop-in promises),
+        ``"difference"`` for the smooth kernels (both forms agree to 8e-15 there)."""
         self.kernel_str = kernel
+        if distance_form is None:
+            distance_form = DEFAULT_DISTANCE_FORM.get(kernel, "difference")
         self.distance_form = distance_form
         if kernel in _REFERENCE_ONLY:
             raise NotImplementedError(

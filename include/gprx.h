@@ -84,7 +84,9 @@ int gprx_synchronize(gprx_handle h);
  *   GPRX_DIST_EXPANDED              r2 = |a/l|^2 + |b/l|^2 - 2 (a/l).(b/l): the literal arithmetic of gpflow's
  *                                   square_distance, which the kernels constructed at gpr.py:298 evaluate.
  * The two agree to rounding for RBF / Matern32 / Matern52; for Matern12 / Exponential (not differentiable at r = 0) the
- * expanded form leaves r2 ~ 1e-15 on coincident points, which moves outputs by 1e-9 .. 1e-8. */
+ * expanded form leaves r2 ~ 1e-15 on coincident points, which moves outputs by 1e-9 .. 2.5e-8:
+ * a caller that promises 1e-8 against gpflow selects GPRX_DIST_EXPANDED for those two kernels -- the host class
+ * gpras_amd.gpr.GPRAS does so by default. */
 #define GPRX_DIST_DIFFERENCE 0
 #define GPRX_DIST_EXPANDED 1
 int gprx_set_distance_form(gprx_handle h, int form);

@@ -2,9 +2,13 @@
 row N1: ``PreProcessor.transform`` (/root/reference/gpras/preprocess.py:1009-1038), ``wse_2_depth`` (:1040-1044),
 ``reverse_transform`` (:1052-1085) and ``_linear_transform_for_var`` (:1087-1094).
 
-PARITY UNPINNED against the real reference for the same reason as the GP oracle: the reference module imports gpflow /
-tensorflow at import time through its package and has no tests or fixtures; these functions are plain numpy in the
-reference, and this file follows them operation by operation (same order of subtract / weight / dot / divide).
+PINNED by outputs of the reference itself (round 3): ``tests/golden/make_golden_pca_ref.py`` imports
+``/root/reference/gpras/preprocess.py`` in the build container (inert recording modules stand in for the absent third-party
+imports of that file, and the script asserts none of them was touched while the recorded calls ran), builds ``PreProcessor``
+objects through the reference's constructor and records ``transform`` / ``reverse_transform`` / ``_linear_transform_for_var``
+on 12 seeded states (wse / depth / velocity x weighted / unweighted, dry cells) into ``tests/golden/pca_ref_golden.npz``;
+``tests/test_pca.py`` holds this file to those outputs BIT FOR BIT.  These functions are plain numpy in the reference, and
+this file follows them operation by operation (same order of subtract / weight / dot / divide).
 
 State = what a fitted reference PreProcessor holds (preprocess.py:868-927): ``dry`` (bool per cell), ``elevations``
 (per cell), and over the wet cells ``input_mean``, ``weights`` (or None), ``eofs`` (k, n_wet); ``x_mean``, ``x_std`` (k);

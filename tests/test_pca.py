@@ -187,3 +187,65 @@ def test_gpu_projection_random_shapes(seed):
     assert np.max(np.abs(full - fr)) <= 1e-13 * np.max(np.abs(fr)), (n_cells, k, t, mode)
     assert np.max(np.abs(vfull - vr)) <= 1e-13 * max(np.max(np.abs(vr)), 1e-300), (n_cells, k, t, mode)
     p.close()
+
+
+# ---- row N1 pinned by the REFERENCE's own outputs -----------------------------------------------------
+# tests/golden/pca_ref_golden.npz was written by tests/golden/make_golden_pca_ref.py, which imports
+# /root/reference/gpras/preprocess.py in the build container and runs PreProcessor.transform / reverse_transform /
+# _linear_transform_for_var (:1009-1094) on seeded fitted states; pca_ref_cases() regenerates the inputs here.
+import json  # noqa: E402
+import os  # noqa: E402
+import sys  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_pca_ref as pca_gen  # noqa: E402  (it reads the reference only in main())
+
+PCA_GOLD = np.load(os.path.join(HERE, "golden", "pca_ref_golden.npz"))
+PCA_CASES = pca_gen.pca_ref_cases()
+
+
+def _oracle_args(c):
+    kw = c["kwargs"]
+    return (c["dry"], kw["elevations"], kw["input_mean"], kw["weights"], kw["eofs"], kw["x_mean"], kw["x_std"], c["mode"])
+
+
+def test_reference_fixture_is_what_it_says():
+    meta = json.loads(str(PCA_GOLD["meta_json"]))
+    assert meta["reference_file"] == "gpras/preprocess.py" and len(PCA_CASES) == 12
+    # the unweighted constructor state of the reference cannot transform (np.empty(0) weights, preprocess.py:916, :1030)
+    assert set(meta["unweighted_constructor_state_raises"].values()) == {"ValueError"}
+    assert {"geopandas", "gpflow", "tensorflow", "hecdss"} <= set(meta["inert_modules"])
+
+
+@pytest.mark.parametrize("name", sorted(PCA_CASES))
+def test_oracle_equals_reference_outputs_bit_for_bit(name):
+    c = PCA_CASES[name]
+    args = _oracle_args(c)
+    assert np.array_equal(opca.transform(c["x"].copy(), *args), PCA_GOLD[f"{name}/transform"])
+    assert np.array_equal(opca.reverse_transform(c["mean"].copy(), None, *args), PCA_GOLD[f"{name}/reverse_mean_only"])
+    full, vfull = opca.reverse_transform(c["mean"].copy(), c["var"].copy(), *args)
+    assert np.array_equal(full, PCA_GOLD[f"{name}/reverse_full"]) and np.array_equal(vfull, PCA_GOLD[f"{name}/reverse_var"])
+    kw = c["kwargs"]
+    assert np.array_equal(opca.linear_transform_for_var(kw["weights"], kw["eofs"], kw["x_std"]), PCA_GOLD[f"{name}/linear_transform_for_var"])
+    if c["mode"] == "depth":
+        assert np.array_equal(opca.wse_2_depth(c["x"].copy(), kw["elevations"]), PCA_GOLD[f"{name}/wse_2_depth"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(PCA_CASES))
+def test_gpu_projector_against_reference_outputs(name):
+    from gpras_amd.preprocess import EOFProjector
+
+    c = PCA_CASES[name]
+    proj = EOFProjector(*_oracle_args(c))
+    want = PCA_GOLD[f"{name}/transform"]
+    z = proj.transform(c["x"].copy())
+    assert z.shape == want.shape and np.max(np.abs(z - want)) <= 1e-11 * np.max(np.abs(want))
+    want_full, want_var = PCA_GOLD[f"{name}/reverse_full"], PCA_GOLD[f"{name}/reverse_var"]
+    only = proj.reverse_transform(c["mean"].copy())
+    assert np.max(np.abs(only - PCA_GOLD[f"{name}/reverse_mean_only"])) <= 1e-13 * np.max(np.abs(want_full))
+    full, vfull = proj.reverse_transform(c["mean"].copy(), c["var"].copy())
+    assert np.max(np.abs(full - want_full)) <= 1e-13 * np.max(np.abs(want_full))
+    assert np.max(np.abs(vfull - want_var)) <= 1e-13 * np.max(np.abs(want_var))
+    assert np.array_equal(vfull[:, c["dry"]], want_var[:, c["dry"]])  # exact zeros on the always-dry cells
