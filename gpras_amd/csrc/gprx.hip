@@ -25,7 +25,8 @@
 #include "metrics.h"
 #include "pca.h"
 #include "potrf.h"
-#include "potrf_large.h"
+#include "potrf_cell.h"
+#include "potrf_dag.h"
 #include "sgpr.h"
 #include "solve.h"
 
@@ -57,7 +58,8 @@ struct gprx_ctx {
   int64_t n = 0, m = 0, np = 0, mp = 0;
   int d = 0, kid = 0, ard = 0, nlen = 1, ntheta = 3, n_units = 0;
   int dist_form = 0;  // GPRX_DIST_DIFFERENCE / GPRX_DIST_EXPANDED
-  PotrfLarge large;   // streams and scratch of the large-matrix schedule (potrf_large.h), created on first use
+  DagPlan dag;        // task list and state words of the tile-DAG factorisation of a lone matrix (potrf_dag.h), created on first use
+  bool dag_used = false;  // the current single factorisation ran through it: its abort word travels with the results
   PotrfTuning tune;   // schedule knobs of this handle: the process defaults at creation, then gprx_set_handle_tuning
   int predict_path = 0;
   std::string err;
@@ -279,12 +281,20 @@ int ensure_lookahead(gprx_handle h) {
   return GPRX_OK;
 }
 
-bool use_large_schedule(const PotrfTuning& tune, int np) {
-  // off by default: measured on MI355X (N = 16384: 36.1 ms against 30.7 ms for the panel-over-all-rows schedule with a 64 x 64
-  // TAIL tile; N = 8192: 9.1 against 6.6 ms) -- the per-block chain (16 panels, 8 inversion GEMMs, copy, triangular GEMM,
-  // HEAD) is longer than the bulk update it should hide behind.  "large_min" (gprx_set_tuning) enables it from a given size.
-  const int lim = tune.large_min;
-  return lim > 0 && np >= lim && np > 1024;
+// "dag" (gprx_set_tuning) = 1: a lone matrix takes the tile-DAG factorisation (potrf_dag.h: one persistent launch, the dependent
+// chain in one workgroup, tile tasks ordered by version counters).  Opt-in: measured on MI355X at N = 4096 it reaches 2.33 ms
+// against 2.16 ms for the launch-per-panel schedule (every row block has a dependent TRSM -> update pair
+// per column, each costing two or more ~2 us memory hops, as much as the 1.7 us of MFMA work in a 64^3 tile).
+bool use_dag(const PotrfTuning& tune, int np) { return tune.dag > 0 && np >= NB; }
+
+// Batched cells: the one-workgroup-per-cell factorisation (potrf_cell.h) for matrices of at most 512 rows once the batch has a
+// workgroup for every CU ("cell_kernel": 1 always, -1 never).  Measured on MI355X (tools/cell_probe.py): N = 200 x 300 cells
+// +11 %, N = 512 x 512 cells +15 % over the batched launch sequence, N = 1024 x 512 cells +1.6 % (both stream every operand from
+// HBM there: 512 cells x 8 MB), so larger matrices or fewer cells keep the launch sequence (bit-identical to single calls).
+bool use_cell_kernel(const PotrfTuning& tune, int np, int cells) {
+  if (tune.cell_kernel < 0) return false;
+  if (tune.cell_kernel > 0) return true;
+  return np <= 512 && cells >= 256;
 }
 
 int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookahead = true, bool capture = false) {
@@ -322,9 +332,10 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[1], st));
   HIPCHK(h, hipMemsetAsync(h->info, 0, sizeof(int), st));
   if (h->profiling) h->prof.reset();
-  if (use_large_schedule(h->tune, np) && !capture) {
-    // one large matrix: block columns, the panel chain confined to the diagonal block on reserved CUs (potrf_large.h)
-    HIPCHK(h, potrf_lower_large(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->large, h->tune));
+  h->dag_used = false;
+  if (use_dag(h->tune, np) && !capture && !h->profiling) {
+    HIPCHK(h, potrf_dag(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dag));
+    h->dag_used = true;
   } else {
     HIPCHK(h, potrf_lower(st, h->Kmat.p, ld, np, NB, h->invD.p, h->info, h->dstage.p, h->profiling ? &h->prof : nullptr,
                           lookahead ? &h->pstreams : nullptr, 1, 0, 0, &h->tune));
@@ -337,6 +348,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[3], st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 64, h->red.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 72, h->info, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (h->dag_used) HIPCHK(h, hipMemcpyAsync(h->pin + 73, h->dag.state + DAG_ABORT, sizeof(int), hipMemcpyDeviceToHost, st));
   h->factorized = false;
   h->cur_unit = unit;
   h->variance = t.variance;
@@ -357,7 +369,7 @@ std::mutex& capture_mutex() {
 // the device (4 hardware queues, each cell ~1.8x slower under 4-way sharing), the replay mainly frees the host.
 int exact_factorize_replay(gprx_handle h, int unit, const Theta& t) {
   static const bool no_graph = getenv("GPRX_NO_GRAPH") != nullptr;  // escape hatch: eager launches
-  if (h->d > 64 || h->profiling || no_graph || use_large_schedule(h->tune, (int)h->np)) return exact_factorize_enqueue(h, unit, t, false);
+  if (h->d > 64 || h->profiling || no_graph || false) return exact_factorize_enqueue(h, unit, t, false);
   auto it = h->graphs.find(unit);
   if (it == h->graphs.end()) {
     // buffers must exist before capture: a first eager pass allocates them (and is a valid fit by itself)
@@ -429,6 +441,14 @@ int exact_factorize_finish(gprx_handle h, double* lml_out) {
   int info = 0;
   std::memcpy(&info, h->pin + 72, sizeof(int));
   if (h->profiling) summarize_profile(h);
+  if (h->dag_used) {
+    int gave_up = 0;
+    std::memcpy(&gave_up, h->pin + 73, sizeof(int));
+    if (gave_up != 0) {
+      h->factorized = false;
+      return fail(h, GPRX_EHIP, "tile-DAG factorisation: a dependency wait timed out (scheduler gave up, code " + std::to_string(gave_up) + ")");
+    }
+  }
   if (info != 0) {
     h->factorized = false;
     char msg[128];
@@ -565,12 +585,9 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
-    if (use_large_schedule(h->tune, np)) {
-      // the schedule depends on the matrix size alone (bit-identical to single calls): large matrices one after the other,
-      // each fills the chip by itself
-      for (int c = 0; c < cnt; ++c)
-        HIPCHK(h, potrf_lower_large(gs, K0 + (int64_t)c * cs, ld, np, NB, K0 + (int64_t)c * cs + h->off_invd, info0 + (int64_t)c * 2 * CELL_RES,
-                                    K0 + (int64_t)c * cs + h->off_stage, h->large, h->tune));
+    if (use_cell_kernel(h->tune, np, cnt) && !h->profiling) {
+      // small matrices in many cells: one workgroup owns one cell from the first column to the last (potrf_cell.h)
+      HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES));
     } else {
       HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
                             2 * CELL_RES, &h->tune));
@@ -1410,7 +1427,7 @@ int gprx_destroy(gprx_handle h) {
   for (auto& ev : h->ev)
     if (ev) hipEventDestroy(ev);
   h->pstreams.destroy();
-  h->large.destroy();
+  h->dag.destroy();
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return GPRX_OK;
@@ -2664,14 +2681,15 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   HIPCHK(nullptr, ps.init());
   double* dstage = nullptr;
   HIPCHK(nullptr, hipMalloc((void**)&dstage, sizeof(double) * np * STAGE_LD));
-  PotrfLarge large;
-  hipError_t e = use_large_schedule(potrf_tuning(), (int)np)
-                     ? potrf_lower_large(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, large, potrf_tuning())
-                     : potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
+  DagPlan dag;
+  const bool by_dag = use_dag(potrf_tuning(), (int)np) && extra % NB == 0;
+  hipError_t e = by_dag ? potrf_dag(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dag)
+                        : potrf_lower(st, a_dev, lda, (int)np, (int)extra, inv_diag_dev, dinfo, dstage, nullptr, &ps);
   hipError_t e2 = hipStreamSynchronize(st);
-  for (hipStream_t side : {ps.aux, large.chain, large.gemm, large.tail})
-    if (side && e2 == hipSuccess) e2 = hipStreamSynchronize(side);
-  large.destroy();
+  if (ps.aux && e2 == hipSuccess) e2 = hipStreamSynchronize(ps.aux);
+  int gave_up = 0;
+  if (by_dag && e == hipSuccess && e2 == hipSuccess) copy_sync(&gave_up, dag.state + DAG_ABORT, sizeof(int), hipMemcpyDeviceToHost);
+  dag.destroy();
   hipFree(dstage);
   ps.destroy();
   hipStreamDestroy(st);
@@ -2679,7 +2697,19 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
   hipFree(dinfo);
   HIPCHK(nullptr, e);
   HIPCHK(nullptr, e2);
+  if (gave_up) return fail(nullptr, GPRX_EHIP, "tile-DAG factorisation: a dependency wait timed out");
   return *info_host ? fail(nullptr, GPRX_ENOTPD, "matrix not positive definite") : GPRX_OK;
+}
+
+// development aid (GPRX_DAG_STAMPS=1): the stamps of the handle's last tile-DAG factorisation; returns the number of words
+extern "C" int gprx_dag_stamps(gprx_handle h, unsigned long long* out, int max_words, int* T, int* grid) {
+  if (!h || !h->dag.stamps) return 0;
+  const int n = (int)std::min<size_t>(h->dag.stamp_words, (size_t)max_words);
+  hipStreamSynchronize(h->stream);
+  copy_sync(out, h->dag.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+  if (T) *T = h->dag.T;
+  if (grid) *grid = h->dag.grid;
+  return n;
 }
 
 #ifdef GPRX_PANEL_STAMPS
@@ -2699,7 +2729,8 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "panel_occ" && (value == 0 || value == 2 || value == 3)) t.panel_occ = value;
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
-  else if (k == "large_min" && (value == 0 || (value >= 2048 && value % 64 == 0))) t.large_min = value;
+  else if (k == "dag" && value >= -1 && value <= 1) t.dag = value;
+  else if (k == "cell_kernel" && value >= -1 && value <= 1) t.cell_kernel = value;
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
   else return false;
   return true;

@@ -956,7 +956,8 @@ struct PotrfTuning {
   int panel_occ = 0;     // 3: panel kernel compiled for 3 workgroups per CU (168 registers, small spills) instead of 2
   int inblock = 0;       // 1: right-looking K = 64 strips inside an outer block instead of the recursive halving
   int split_panel = 0;   // 1: always the split panel (diagonal workgroup + rows kernel), -1: never, 0: from 24 cells per launch on
-  int large_min = 0;     // matrices of at least this many (padded) rows take the block-column schedule of potrf_large.h (0: never)
+  int cell_kernel = 0;   // batched cells: 1 = always one workgroup per cell (potrf_cell.h), -1 never, 0 = for np <= 1024 and >= 256 cells
+  int dag = 0;           // lone matrices: 1 = the tile-DAG factorisation (potrf_dag.h); 0 / -1 = the launch-per-panel schedule (default)
 };
 inline PotrfTuning& potrf_tuning() {
   static PotrfTuning t = [] {
@@ -968,7 +969,8 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_PANEL_OCC")) v.panel_occ = atoi(e);
     if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
     if (const char* e = getenv("GPRX_SPLIT_PANEL")) v.split_panel = atoi(e);
-    if (const char* e = getenv("GPRX_LARGE_MIN")) v.large_min = atoi(e);
+    if (const char* e = getenv("GPRX_DAG")) v.dag = atoi(e);
+    if (const char* e = getenv("GPRX_CELL_KERNEL")) v.cell_kernel = atoi(e);
     return v;
   }();
   return t;

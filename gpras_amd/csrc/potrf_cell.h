@@ -1,0 +1,125 @@
+// One workgroup factors one whole matrix: the batched Cholesky for SMALL matrices (N <= 1024) in MANY cells.
+//
+// Why: at N = 1024 the launch-per-panel schedule of potrf_lower runs everything at short K -- the whole matrix is one outer
+// block: 63 k fits/s = 0.29 of the fp64 MFMA peak with 512 cells per launch sequence -- and every one of
+// its ~100 launches moves the panel through HBM.  A cell of N = 1024 is 8 MB: one workgroup can own it from the first column to
+// the last with NO inter-workgroup dependency, two workgroups per CU hiding each other's dependent chains:
+//   for block column j:  A(i,j) -= sum_{c<j} L(i,c) L(j,c)^T for i >= j (left-looking: ONE pass with K = 64 j per tile, four row
+//                        tiles per pass sharing the B operand -- dag_panel of potrf_dag.h);
+//                        the diagonal block through the eight sub-panel steps of the tile-DAG chain (L(j,j) and its inverse);
+//                        L(i,j) = A(i,j) L(j,j)^-T for i > j (tile products against the inverse).
+// Each element of the lower triangle is read and written once per block column it belongs to plus once per use as an operand
+// -- all of it from this CU's L1 / the XCD's L2 (plain accesses: nobody else touches the cell).
+// Arithmetic: the same tile products and the same sub-panel substitution as the other schedules, but a tile receives its whole
+// update as one sum (C - sum, one rounding) and rows are solved against the explicit 64 x 64 inverse: results agree with
+// potrf_lower to rounding (tested), not bit for bit.
+#pragma once
+#include "potrf_dag.h"
+
+namespace gprx {
+
+struct CellArgs {
+  double* A;         // cell 0; cells are `cs` doubles apart
+  int64_t lda;
+  int T, R;          // 64-column blocks, 64-row blocks (T + right-hand-side blocks)
+  double* inv_diag;  // cell 0 (T blocks of 64 x 64), cs apart
+  int* info;         // cell 0, info_stride ints apart
+  int64_t cs;
+  int info_stride;
+  int col_base;
+};
+
+// the diagonal block (j, j): chain_step<0..7> on [64 diagonal rows | 64 identity rows] -> L(j,j) in place, L(j,j)^-1 to inv_diag
+__device__ __forceinline__ int cell_diag(double* __restrict__ Ajj, int64_t lda, double* __restrict__ inv, double* __restrict__ smem) {
+  ChainCtx c;
+  c.sIn = smem;
+  c.sX = smem + 128 * PSUB;
+  double* sT = smem + 2 * 128 * PSUB;
+  c.tid = threadIdx.x;
+  const int lane = c.tid & 63;
+  c.wave = c.tid >> 6;
+  c.g = lane >> 4;
+  c.r = lane & 15;
+  c.bad = 0;
+  const int wave = c.wave, g = c.g, r = c.r, tid = c.tid;
+  const unsigned ldb = (unsigned)lda * 8u;
+  const unsigned off_cd = (unsigned)(16 * wave + g) * ldb + (unsigned)r * 8u;
+  const __amdgpu_buffer_rsrc_t rs = dag_rsrc(Ajj);
+  d4 acc[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * wave + g + 4 * q, col = 16 * kt + r;
+      const double v = ld1_sc1<false>(rs, off_cd, (unsigned)(4 * q) * ldb + (unsigned)kt * 128u);
+      acc[0][kt][q] = (col > row) ? 0.0 : v;
+      acc[1][kt][q] = (col == row) ? 1.0 : 0.0;
+    }
+  chain_step<0>(acc, c);
+  chain_step<1>(acc, c);
+  chain_step<2>(acc, c);
+  chain_step<3>(acc, c);
+  chain_step<4>(acc, c);
+  chain_step<5>(acc, c);
+  chain_step<6>(acc, c);
+  chain_step<7>(acc, c);
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      st1_sc1<false>(rs, off_cd, acc[0][kt][q], (unsigned)(4 * q) * ldb + (unsigned)kt * 128u);
+      sT[(16 * kt + r) * DAG_T_LD + 16 * wave + g + 4 * q] = acc[1][kt][q];
+    }
+  lds_barrier();
+  const __amdgpu_buffer_rsrc_t ri = dag_rsrc(inv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int q = tid + 256 * e;
+    st2_sc1<false>(ri, (unsigned)tid * 16u, *reinterpret_cast<const d2*>(sT + (q >> 5) * DAG_T_LD + 2 * (q & 31)), (unsigned)e * 4096u);
+  }
+  return c.bad;
+}
+
+__global__ __launch_bounds__(256, 2) void potrf_cell_kernel(CellArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[DAG_SMEM];
+  const int64_t off = (int64_t)blockIdx.x * p.cs;
+  const TileCtx tc{p.A + off, p.lda, p.inv_diag + off};
+  int first_bad = 0;
+  for (int j = 0; j < p.T; ++j) {
+    if (j > 0) {
+      for (int i0 = j; i0 < p.R; i0 += DAG_NI) {
+        const int ni = p.R - i0 < DAG_NI ? p.R - i0 : DAG_NI;
+        dag_panel<false, false>(tc, i0, ni, j, 0, j, smem);
+        __syncthreads();  // (LDS images free; the stores are visible to this workgroup's later loads)
+      }
+    }
+    const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
+    if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
+    __syncthreads();
+    for (int i0 = j + 1; i0 < p.R; i0 += DAG_NI) {
+      const int ni = p.R - i0 < DAG_NI ? p.R - i0 : DAG_NI;
+      dag_panel<true, false>(tc, i0, ni, j, j, j + 1, smem);
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && first_bad > 0) atomicCAS(p.info + (int64_t)blockIdx.x * p.info_stride, 0, p.col_base + first_bad);
+}
+
+// `batch` matrices of np x np (+ extra right-hand-side rows), cs doubles apart; info words info_stride ints apart (zeroed by the caller)
+inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info, int batch, int64_t cs,
+                              int info_stride, int col_base = 0) {
+  CellArgs a;
+  a.A = A;
+  a.lda = lda;
+  a.T = np / NB;
+  a.R = a.T + extra / NB;
+  a.inv_diag = inv_diag;
+  a.info = info;
+  a.cs = cs;
+  a.info_stride = info_stride;
+  a.col_base = col_base;
+  hipLaunchKernelGGL(potrf_cell_kernel, dim3(batch), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace gprx

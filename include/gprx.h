@@ -329,8 +329,10 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
  * "inblock" (1: right-looking K = 64 strips inside an outer block instead of recursive halving), "split_panel"
  * (1: always one diagonal workgroup + a rows-only kernel per panel, -1: never; default: from 24 cells per launch on).
- * "large_min" (rows from which ONE matrix takes the block-column schedule -- diagonal block factored by the panel chain on
- * reserved CUs, the rows below it by one triangular GEMM against the block's explicit inverse; default 0 = never: measured slower than the default schedule on MI355X, kept as a tested option).
+ * "dag" (1: ONE matrix is factored by the tile-DAG kernel -- a single persistent launch, the dependent chain of diagonal
+ * blocks in one workgroup, every other tile task claimed from a queue and ordered by per-tile version counters in device memory;
+ * deterministic, within rounding of the default; default 0 = the launch-per-panel schedule, which measured faster on MI355X:
+ * DESIGN.md section 7.2).
  * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical.
  * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution. */
 int gprx_set_tuning(const char* key, int value);

@@ -208,48 +208,81 @@ def test_split_panel_is_bit_identical_to_the_fused_panel(lib):
         assert rel_err(a, b) < 1e-13
 
 
-@pytest.mark.parametrize("n,extra,outer", [(2048, 64, 512), (3136, 0, 1024), (2112, 128, 1024)])
-def test_potrf_block_column_schedule_for_large_matrices(lib, n, extra, outer):
-    """The large-matrix schedule (potrf_large.h: diagonal block by the panel chain on reserved CUs, rows below by one
-    triangular GEMM against the block's explicit inverse), forced at small sizes through the "large_min" knob: factor,
-    right-hand-side rows and the 64 x 64 inverse blocks against scipy, reproducible run to run, failing pivot reported with its
-    global index."""
+@pytest.mark.parametrize("n,extra,ni", [(64, 64, 4), (192, 0, 4), (2048, 64, 4), (3136, 0, 2), (2112, 128, 1), (4096, 64, 4)])
+def test_potrf_tile_dag(lib, n, extra, ni, monkeypatch):
+    """The tile-DAG factorisation of a lone matrix (potrf_dag.h: one persistent launch, chain workgroup + task-queue workers,
+    per-tile version counters), selected through the "dag" knob: factor, right-hand-side rows and the 64 x 64 inverse blocks
+    against scipy; BIT-IDENTICAL run to run (a stale hand-off between workgroups would show as a differing factor -- the order
+    of the updates of a tile is fixed by its version counter, so timing cannot change the result); within rounding of the
+    launch-per-panel schedule; failing pivot reported with its global index."""
+    monkeypatch.setenv("GPRX_DAG_NI", str(ni))  # tiles per panel task (read when the plan is built: every call here builds one)
     rng = np.random.default_rng(n)
     g = rng.standard_normal((n, 80))
     spd = g @ g.T / 80 + np.eye(n)
     rhs = rng.standard_normal((extra, n))
     L_ref = cholesky(spd, lower=True)
     full = np.vstack([spd, rhs])
+
+    def run(dag):
+        check(lib.gprx_set_tuning(b"dag", dag))
+        dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
+        info = C.c_int(0)
+        check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
+        out, inv = dA.to_array((n + extra, n)), dI.to_array((n // 64, 64, 64))
+        dA.free()
+        dI.free()
+        return out, inv
+
     try:
-        check(lib.gprx_set_tuning(b"large_min", 2048))
-        check(lib.gprx_set_tuning(b"outer_block", outer))
         first = None
-        for _ in range(2):
-            dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
-            info = C.c_int(0)
-            check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
-            out = dA.to_array((n + extra, n))
-            inv = dI.to_array((n // 64, 64, 64))
+        for _ in range(3):
+            out, inv = run(1)
             assert rel_err(np.tril(out[:n]), L_ref) < 1e-11
             if extra:
                 assert rel_err(out[n:], solve_triangular(L_ref, rhs.T, lower=True).T) < 1e-11
-            for b in (0, n // 128, n // 64 - 1):
+            for b in sorted({0, n // 128, n // 64 - 1}):
                 blk = L_ref[64 * b : 64 * b + 64, 64 * b : 64 * b + 64]
                 assert rel_err(inv[b], np.linalg.inv(blk)) < 1e-10
+            for b0 in range(0, n, 64):  # explicit zeros above the diagonal inside the diagonal tiles (the triangular products rely on them)
+                assert np.all(np.triu(out[b0 : b0 + 64, b0 : b0 + 64], 1) == 0.0)
             if first is None:
                 first = out
             else:
-                assert np.array_equal(np.tril(out[:n]), np.tril(first[:n]))
+                assert np.array_equal(np.tril(out[:n]), np.tril(first[:n])) and np.array_equal(out[n:], first[n:])
+        base, _ = run(0)
+        assert rel_err(np.tril(first[:n]), np.tril(base[:n])) < 1e-12
+        if n > 1500:
+            bad = spd.copy()
+            bad[1500, 1500] = -1.0  # not positive definite: the pivot index is global, not relative to its diagonal block
+            check(lib.gprx_set_tuning(b"dag", 1))
+            dA, dI = DeviceBuffer.from_array(np.vstack([bad, rhs])), DeviceBuffer(n * 64 * 8)
+            info = C.c_int(0)
+            rc = lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info))
+            assert rc == _lib.GPRX_ENOTPD and info.value == 1501
             dA.free()
             dI.free()
-        bad = spd.copy()
-        bad[1500, 1500] = -1.0  # not positive definite: the pivot index is global, not relative to its diagonal block
-        dA, dI = DeviceBuffer.from_array(np.vstack([bad, rhs])), DeviceBuffer(n * 64 * 8)
-        info = C.c_int(0)
-        rc = lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info))
-        assert rc == _lib.GPRX_ENOTPD and info.value == 1501
-        dA.free()
-        dI.free()
     finally:
-        lib.gprx_set_tuning(b"large_min", 0)
-        lib.gprx_set_tuning(b"outer_block", 0)
+        lib.gprx_set_tuning(b"dag", 0)
+
+
+def test_fit_through_the_tile_dag_equals_the_launch_schedule(lib):
+    """gprx_factorize + predict with the handle's "dag" knob on: loss and predictions within rounding of the default schedule."""
+    from gpras_amd.model import NOISE_LOWER, softplus_inv
+    from gpras_amd.synth import make_regression
+
+    x, y, xs = make_regression(1500, 6, n_outputs=1, n_test=300, config=2, unit=4)
+    theta = np.ascontiguousarray([softplus_inv(1.1), softplus_inv(0.9), softplus_inv(0.2 - NOISE_LOWER)], dtype=np.float64)
+    res = {}
+    for dag in (0, 1):
+        h = C.c_void_p()
+        check(lib.gprx_create(0, 1500, 6, 0, _lib.KERNEL_IDS["Matern32"], 0, C.byref(h)))
+        check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+        check(lib.gprx_set_handle_tuning(h, b"dag", dag), h)
+        loss = C.c_double()
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss)), h)
+        mean, var = np.empty(300), np.empty(300)
+        check(lib.gprx_predict(h, ptr(xs), 300, ptr(mean), ptr(var), 1), h)
+        res[dag] = (loss.value, mean, var)
+        lib.gprx_destroy(h)
+    assert abs(res[1][0] - res[0][0]) <= 1e-12 * abs(res[0][0])
+    assert rel_err(res[1][1], res[0][1]) < 1e-11 and rel_err(res[1][2], res[0][2]) < 1e-11
