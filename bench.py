@@ -71,8 +71,54 @@ def parse_args():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: this process -- which has made NO GPU call -- starts N fresh rank
+    processes (RANK / LOCAL_RANK / WORLD_SIZE and a private rendezvous prefix in the environment), waits for them and exits
+    with the worst of their codes.  Rank 0 inherits stdout (the JSON line).  No torch in any of them."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="gprx_bench_")
+    procs = []
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), GPRX_ID_FILE=os.path.join(tmp, "rccl"),
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        codes = []
+        for pr in procs:
+            try:
+                codes.append(pr.wait(timeout=3000))
+            except subprocess.TimeoutExpired:
+                pr.kill()  # (exactly the process started above)
+                codes.append(124)
+        return max(codes)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def mapped_runtimes():
+    """Distinct HIP / RCCL libraries mapped into this process (one HIP runtime per rank is the point of the torch-free launch)."""
+    libs = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                name = ln.split()[-1]
+                if "libamdhip64" in name or "librccl" in name:
+                    libs.add(name)
+    except OSError:
+        pass
+    return sorted(libs)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
     # RCCL and the HIP runtime print banners to stdout: keep stdout for the one JSON line only
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -81,48 +127,45 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or "RANK" in os.environ
-    torch = dist = None
-    if distributed:
-        # torch first: libgprx.so then binds to the HIP runtime torch already loaded (same soname)
-        import torch  # noqa: PLC0415
-        import torch.distributed as dist  # noqa: PLC0415
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import fcntl
 
     from gpras_amd import _build, _lib
     from gpras_amd._lib import DeviceBuffer, check, ptr
     from gpras_amd.synth import make_regression
 
-    if rank == 0:
+    with open(os.path.join(ROOT, ".bench_build.lock"), "w") as lock:  # one rank builds (normally nothing to do), the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
         _build.build()
-    if distributed:
-        dist.barrier()
     lib = _lib.load()
     device = local_rank if distributed else 0
-    comm = None
-    if distributed:
-        # the job's one data-path collective runs behind the C ABI (gprx_comm_*: RCCL loaded by libgprx.so, device-resident
-        # buffers); torch.distributed only launches the ranks, carries the 128-byte RCCL id and provides the timing barrier
-        from gpras_amd.comm import Communicator
+    # Ranks are launched by `python -m torch.distributed.run` (the driver) or by spawn_ranks above; either way THIS process never
+    # imports torch: RANK / LOCAL_RANK / WORLD_SIZE come from the environment, the 128-byte RCCL id travels through files
+    # (gpras_amd.comm.file_rendezvous: every rank first reports that it can load RCCL, so nobody blocks in ncclCommInitRank
+    # behind a rank that cannot), timing barriers and the maximum over ranks go through gprx_comm_* -- ONE HIP runtime and ONE
+    # RCCL per rank (torch's own HIP / HSA / RCCL tree beside ROCm's was the source of the round-2 failures).
+    # GPRX_BENCH_TORCH=1 (or a failed rendezvous, agreed by all ranks) selects the older path through torch.distributed.
+    torch = dist = comm = None
+    comm_error = ""
+    launcher = "single process"
+    if distributed and os.environ.get("GPRX_BENCH_TORCH") != "1":
+        from gpras_amd.comm import Communicator, default_id_prefix
 
-        # (every rank must take the same path: the outcome of the communicator's creation is agreed through the process group,
-        # and a failure -- which cannot be rehearsed with more than one GPU here -- degrades to torch.distributed's all_gather
-        # instead of costing the whole scaling record; the JSON line says which collective ran)
-        comm_error = ""
         try:
-            comm = Communicator.bootstrap(device, rank, world)
+            comm = Communicator.bootstrap(device, rank, world, id_file=default_id_prefix())
+            launcher = "torch-free ranks: environment + file rendezvous, gprx_comm_* (RCCL behind the C ABI) for barriers, max and the gather"
         except Exception as exc:  # noqa: BLE001
             comm, comm_error = None, f"{type(exc).__name__}: {exc}"
-        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
-            comm_error = comm_error or "another rank could not create its communicator"
+    if distributed and comm is None:
+        import torch  # noqa: PLC0415
+        import torch.distributed as dist  # noqa: PLC0415
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        launcher = f"torch.distributed fallback ({comm_error or 'GPRX_BENCH_TORCH=1'})"
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
     # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
@@ -146,8 +189,11 @@ def main():
     loss = C.c_double()
 
     def sync_all():
+        # device work of this rank done, then all ranks arrived (RCCL all-reduce + stream wait), then nothing left in flight
         check(lib.gprx_synchronize(h), h)
-        if distributed:
+        if comm is not None:
+            comm.barrier()
+        elif distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -183,9 +229,12 @@ def main():
     if distributed:
         all_losses = d_all.to_array((world, cells)) if comm is not None else torch.stack(gathered).cpu().numpy()
         assert np.array_equal(all_losses[rank], losses) and np.all(np.isfinite(all_losses))
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())  # the slowest rank's time
+        if comm is not None:
+            elapsed = comm.max(elapsed)  # the slowest rank's time
+        else:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
     fits_per_s = world * cells * args.steps / elapsed
 
     result = {
@@ -210,6 +259,8 @@ def main():
             "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end",
             "collective": ("none (one process)" if not distributed else "gprx_comm_all_gather (RCCL behind the C ABI, device-resident buffers)" if comm is not None
                            else f"torch.distributed all_gather (fallback: {comm_error})"),
+            "launcher": launcher,
+            "hip_and_rccl_libraries_mapped": mapped_runtimes(),
         },
     }
 
@@ -587,9 +638,10 @@ def main():
             result["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
 
     lib.gprx_destroy(h)
-    if distributed:
-        if comm is not None:
-            comm.close()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    elif distributed:
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()

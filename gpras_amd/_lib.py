@@ -57,6 +57,7 @@ PROTOTYPES = {
     "gprx_last_profile": (C.c_int, [_vp, _dp]),
     "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "gprx_adam_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "gprx_comm_runtime_check": (C.c_int, [C.c_int]),
     "gprx_comm_unique_id": (C.c_int, [_vp]),
     "gprx_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "gprx_comm_destroy": (C.c_int, [_vp]),
@@ -87,6 +88,7 @@ PROTOTYPES = {
     "gprx_pca_transpose_dev": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "gprx_metrics": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "gprx_metrics_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "gprx_kmeans_pp": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp, C.c_int, C.c_int, _i64, _vp, _vp]),
     "gprx_kmeans_lloyd": (C.c_int, [C.c_int, _vp, _i64, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _ip]),
     "gprx_gather_rows": (C.c_int, [C.c_int, _vp, _i64, _i64, _vp, _vp]),
     "gprx_kmat": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _i64, C.c_int, _vp, C.c_double, C.c_double, _vp, _i64, _i64, _i64, C.c_int]),

@@ -38,6 +38,66 @@ def new_unique_id() -> bytes:
     return bytes(buf)
 
 
+def file_rendezvous(prefix: str, rank: int, world: int, status: str, make_id, timeout_s: float = 120.0, max_age_s: float = 900.0) -> bytes:
+    """Torch-free rendezvous over files on a path every rank sees (one node: /tmp): returns the id that rank 0 created.
+
+    1. every rank publishes ``status`` ("ok" or an error text) as ``<prefix>.ready.<rank>`` -- written to a temporary name and
+       renamed, so a reader never sees half a file;
+    2. every rank waits for all ``world`` status files: if ANY rank is not "ok", every rank raises the same RuntimeError and
+       nobody enters the collective initialisation (a rank that cannot load RCCL must not leave the others blocked in
+       ncclCommInitRank);
+    3. rank 0 calls ``make_id()`` and publishes ``<prefix>.id``; the others poll for it.
+    Files carry the wall-clock time of their writing and are ignored when older than ``max_age_s`` (leftovers of an earlier
+    launch that reused the prefix)."""
+
+    def publish(path: str, payload: bytes) -> None:
+        tmp = f"{path}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(repr(time.time()).encode() + b"\n" + payload)
+        os.replace(tmp, path)
+
+    def read_fresh(path: str):
+        try:
+            with open(path, "rb") as f:
+                stamp, _, payload = f.read().partition(b"\n")
+            return payload if time.time() - float(stamp) <= max_age_s else None
+        except (OSError, ValueError):
+            return None
+
+    t0 = time.time()
+
+    def wait_for(path: str, what: str) -> bytes:
+        while True:
+            got = read_fresh(path)
+            if got is not None:
+                return got
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rank {rank}: {what} ({path}) did not appear within {timeout_s:.0f} s")
+            time.sleep(0.02)
+
+    publish(f"{prefix}.ready.{rank}", status.encode())
+    states = [wait_for(f"{prefix}.ready.{r}", f"status of rank {r}").decode() for r in range(world)]
+    bad = {r: st for r, st in enumerate(states) if st != "ok"}
+    if bad:
+        raise RuntimeError(f"the communicator cannot be created on every rank: {bad}")
+    if rank == 0:
+        publish(f"{prefix}.id", make_id())
+    return wait_for(f"{prefix}.id", "the RCCL id of rank 0")
+
+
+def default_id_prefix() -> str:
+    """A rendezvous prefix every rank of ONE launch computes identically and no other launch shares: explicit ``GPRX_ID_FILE``, else
+    /tmp + the launcher's port + its run id + the launcher's pid (the ranks are siblings: children of one ``torch.distributed.run``
+    agent or of ``bench.py``'s own spawner)."""
+    explicit = os.environ.get("GPRX_ID_FILE")
+    if explicit:
+        return explicit
+    import tempfile
+
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    return os.path.join(tempfile.gettempdir(), f"gprx_rccl_{tag}")
+
+
 class Communicator:
     def __init__(self, device: int, rank: int, world: int, unique_id: bytes):
         if len(unique_id) != _lib.UNIQUE_ID_BYTES:
@@ -54,15 +114,19 @@ class Communicator:
         (``broadcast_object_list`` from rank 0), else through ``id_file`` (rank 0 writes it atomically, the others poll)."""
         rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
-        dist = None
-        try:
-            import torch.distributed as tdist
+        # (torch is never imported HERE: a process group can only exist if the caller imported torch itself -- importing it now would
+        # map torch's own HIP / HSA / RCCL tree into a rank that is meant to run on one runtime)
+        import sys
 
-            if tdist.is_available() and tdist.is_initialized():
-                dist = tdist
-        except ImportError:
-            pass
+        dist = sys.modules.get("torch.distributed")
+        if dist is not None and not (dist.is_available() and dist.is_initialized()):
+            dist = None
         if dist is not None:
+            rc = _lib.load().gprx_comm_runtime_check(int(device))
+            states = [None] * world
+            dist.all_gather_object(states, "ok" if rc == _lib.GPRX_OK else f"rank {rank}: libgprx error {rc}")
+            if any(st != "ok" for st in states):
+                raise RuntimeError(f"the communicator cannot be created on every rank: {[st for st in states if st != 'ok']}")
             box = [None]
             if rank == 0:
                 try:
@@ -77,18 +141,14 @@ class Communicator:
             return cls(device, 0, 1, new_unique_id())
         if id_file is None:
             raise RuntimeError("no torch.distributed process group and no id_file: the RCCL id cannot reach the other ranks")
-        if rank == 0:
-            tmp = f"{id_file}.tmp{os.getpid()}"
-            with open(tmp, "wb") as f:
-                f.write(new_unique_id())
-            os.replace(tmp, id_file)
-        t0 = time.time()
-        while not os.path.exists(id_file):
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"rank {rank}: the RCCL id file {id_file} did not appear")
-            time.sleep(0.05)
-        with open(id_file, "rb") as f:
-            return cls(device, rank, world, f.read())
+        # torch-free: readiness of every rank agreed through files before anyone enters ncclCommInitRank
+        rc = _lib.load().gprx_comm_runtime_check(int(device))
+        status = "ok"
+        if rc != _lib.GPRX_OK:
+            msg = _lib.load().gprx_comm_last_error(None)
+            status = f"rank {rank}: {msg.decode() if msg else 'libgprx error ' + str(rc)}"
+        uid = file_rendezvous(id_file, rank, world, status, new_unique_id, timeout_s=timeout_s)
+        return cls(device, rank, world, uid)
 
     # -- lifetime --------------------------------------------------------------------------------------------------
     def close(self):

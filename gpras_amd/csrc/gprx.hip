@@ -2387,6 +2387,67 @@ int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* cen
   return GPRX_OK;
 }
 
+// k-means++ seeding on the device (kmeans.h): x (n, d) host, centred as scikit-learn centres it; xsq = row_norms(x, squared=True);
+// first_id and uniforms ((m - 1) x trials) are the host's RandomState draws.  indices_out: m chosen point indices.
+int gprx_kmeans_pp(int device, const double* x, int64_t n, int d, const double* xsq, int m, int trials, int64_t first_id, const double* uniforms,
+                   int64_t* indices_out) {
+  if (!x || !xsq || !indices_out || (m > 1 && !uniforms)) return fail(nullptr, GPRX_EINVAL, "null argument");
+  if (n <= 0 || d <= 0 || d > 64 || m <= 0 || m > n || trials <= 0 || trials > KPP_MAX_TRIALS || first_id < 0 || first_id >= n || n > (1 << 30))
+    return fail(nullptr, GPRX_EINVAL, "need 0 < m <= n, 0 < d <= 64, 0 < trials <= 16, 0 <= first_id < n");
+  HIPCHK(nullptr, hipSetDevice(device));
+  hipStream_t us = util_stream();
+  if (!us) return fail(nullptr, GPRX_EHIP, "no utility stream");
+  const int nblocks = (int)((n + 255) / 256);
+  double *dx = nullptr, *dsq = nullptr, *dbuf = nullptr, *dpart = nullptr, *duni = nullptr;
+  KppState* dst = nullptr;
+  long long* didx = nullptr;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)dx, (void*)dsq, (void*)dbuf, (void*)dpart, (void*)duni, (void*)dst, (void*)didx})
+      if (q) hipFree(q);
+  };
+  const size_t slab = sizeof(double) * (size_t)trials * n;  // one generation of candidate distance arrays
+  hipError_t e = hipMalloc((void**)&dx, sizeof(double) * (size_t)n * d);
+  if (e == hipSuccess) e = hipMalloc((void**)&dsq, sizeof(double) * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&dbuf, 2 * slab);
+  if (e == hipSuccess) e = hipMalloc((void**)&dpart, sizeof(double) * (size_t)trials * nblocks);
+  if (e == hipSuccess) e = hipMalloc((void**)&duni, sizeof(double) * (size_t)std::max(1, (m - 1) * trials));
+  if (e == hipSuccess) e = hipMalloc((void**)&dst, 2 * sizeof(KppState));
+  if (e == hipSuccess) e = hipMalloc((void**)&didx, sizeof(long long) * m);
+  if (e == hipSuccess) e = hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, us);
+  if (e == hipSuccess) e = hipMemcpyAsync(dsq, xsq, sizeof(double) * n, hipMemcpyHostToDevice, us);
+  if (e == hipSuccess && m > 1) e = hipMemcpyAsync(duni, uniforms, sizeof(double) * (size_t)(m - 1) * trials, hipMemcpyHostToDevice, us);
+  if (e != hipSuccess) {
+    hipStreamSynchronize(us);
+    cleanup();
+    return fail(nullptr, e == hipErrorOutOfMemory ? GPRX_ENOMEM : GPRX_EHIP, std::string("gprx_kmeans_pp staging: ") + hipGetErrorString(e));
+  }
+  double* gen[2] = {dbuf, dbuf + (size_t)trials * n};
+  // distances to the first centre: generation 0, one "candidate"
+  hipLaunchKernelGGL(kpp_dist_kernel, dim3(nblocks, 1), dim3(256), 0, us, (const double*)dx, (int)n, d, (const double*)dsq, (const KppState*)nullptr,
+                     (const double*)nullptr, (int)first_id, gen[0], dpart, nblocks);
+  int cur = 0, prev_trials = 1;
+  for (int c = 1; c <= m; ++c) {
+    // choose among the candidates of centre c - 1 (c == 1: the first centre itself); c < m: candidates of centre c
+    const bool more = c < m;
+    hipLaunchKernelGGL(kpp_select_kernel, dim3(1), dim3(256), 0, us, (int)n, (const double*)gen[cur], (const double*)dpart, nblocks, prev_trials,
+                       c == 1 ? (const KppState*)nullptr : (const KppState*)(dst + ((c - 1) & 1)), (int)first_id, dst + (c & 1),
+                       more ? (const double*)(duni + (size_t)(c - 1) * trials) : (const double*)nullptr, trials, didx + (c - 1));
+    if (!more) break;
+    hipLaunchKernelGGL(kpp_dist_kernel, dim3(nblocks, trials), dim3(256), 0, us, (const double*)dx, (int)n, d, (const double*)dsq,
+                       (const KppState*)(dst + (c & 1)), (const double*)gen[cur], (int)first_id, gen[cur ^ 1], dpart, nblocks);
+    cur ^= 1;
+    prev_trials = trials;
+  }
+  std::vector<long long> idx(m);
+  e = hipMemcpyAsync(idx.data(), didx, sizeof(long long) * m, hipMemcpyDeviceToHost, us);
+  hipError_t e2 = hipStreamSynchronize(us);
+  cleanup();
+  HIPCHK(nullptr, e);
+  HIPCHK(nullptr, e2);
+  for (int c = 0; c < m; ++c) indices_out[c] = idx[c];
+  return GPRX_OK;
+}
+
 int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t cells, const int64_t* idx, double* out) {
   if (!field_dev || !idx || !out) return fail(nullptr, GPRX_EINVAL, "null argument");
   if (rows <= 0 || cells <= 0) return fail(nullptr, GPRX_EINVAL, "rows and cells must be positive");
@@ -2476,6 +2537,11 @@ static int comm_runtime_ready() {
   COMMHIP(nullptr, hipFree(nullptr));  // forces the runtime (context of the current device) into existence
   if (!rccl().load()) return cfail(nullptr, GPRX_ERCCL, rccl().error);
   return GPRX_OK;
+}
+
+int gprx_comm_runtime_check(int device) {
+  COMMHIP(nullptr, hipSetDevice(device));
+  return comm_runtime_ready();
 }
 
 int gprx_comm_unique_id(unsigned char* id128) {

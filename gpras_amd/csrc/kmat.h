@@ -144,8 +144,16 @@ __device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC
       double va = 0.0, vb = 0.0;
       if (k < p.d) {
         const double s = p.ls[k];
-        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] / s;
-        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] / s;
+        if constexpr (FORM == 0) {
+          // one division per thread and pass (its two points share the coordinate k) instead of four: the staging divisions were
+          // ~9 of the ~61 fp64 instructions per output element.  (FORM 1 keeps x / l: it restates gpflow's arithmetic to the bit.)
+          const double inv = 1.0 / s;
+          if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] * inv;
+          if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] * inv;
+        } else {
+          if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] / s;
+          if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] / s;
+        }
       }
       sA[pt][kk] = va;
       sBt[kk][pt] = vb;
@@ -200,6 +208,28 @@ __device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC
   if (p.dparams) {
     p.variance = p.dparams[0];
     p.diag_add = p.diag_const ? diag_keep : p.dparams[1];
+  }
+  // interior tiles (every row and column a real point, no diagonal element): no bounds or diagonal selects -- they were ~10 of the
+  // ~61 fp64-rate instructions per element, and all but 2 T - 1 of the T (T + 1) / 2 lower tiles of a T x T matrix are interior
+  if (i0 + KM_T <= p.n1 && j0 + KM_T <= p.n2 && ti != tj) {  // (i == j only happens inside tiles with ti == tj)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = i0 + wave * 16 + 2 * it + rsub;
+      d2 v;
+#ifdef GPRX_KMAT_NOEXP  // (timing experiments only: where does the time of this kernel go)
+      v.x = p.variance * acc[it][0];
+      v.y = p.variance * acc[it][1];
+#else
+      v.x = p.variance * corr_g<KID>(acc[it][0]);
+      v.y = p.variance * corr_g<KID>(acc[it][1]);
+#endif
+#ifdef GPRX_KMAT_NOSTORE
+      if (v.x == 123.456) *reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j0 + 2 * cp) = v;
+#else
+      *reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j0 + 2 * cp) = v;
+#endif
+    }
+    return;
   }
 #pragma unroll
   for (int it = 0; it < 8; ++it) {

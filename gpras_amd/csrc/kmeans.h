@@ -98,4 +98,116 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const double* __rest
   }
 }
 
+// ---- k-means++ seeding on the device (sklearn.cluster._kmeans._kmeans_plusplus, behind gpr.py:313) -----------------------------
+// The host keeps only what cannot move: the RandomState(0) draws (first index, then n_local_trials uniforms per centre -- they
+// do not depend on the data).  Per centre two launches:
+//   kpp_select_kernel (one workgroup): potentials of the previous candidates (partial sums added in a fixed order), the best
+//       one (first minimum: numpy argmin) becomes a centre and its distance array the current closest_dist_sq; then
+//       searchsorted(cumsum(closest_dist_sq), uniforms * potential): 256 chunk sums, a sequential walk over the chunk sums and
+//       then inside the chunk (first i with cumsum[i] >= v, clipped to n - 1);
+//   kpp_dist_kernel (n / 256 x trials workgroups): squared distances of every point to the candidates in scikit-learn's
+//       expanded form ((-2 x.c + |c|^2) + |x|^2, clamped at 0, the norms as the host's row_norms gave them), minimum with the
+//       current closest distances, partial potentials per workgroup.
+// Rounding differs from scikit-learn's BLAS products in the last bits; an index can only differ when a uniform draw falls
+// within that rounding of a cumulative sum (probability ~ n 1e-16 per draw): the test matrix ends at identical centres.
+constexpr int KPP_MAX_TRIALS = 16;
+struct KppState {
+  int best;                   // index (among the previous candidates) of the one that became a centre
+  int cand[KPP_MAX_TRIALS];   // candidate point indices of the current centre
+  double pot;
+};
+
+// mode 0: distances to ONE given point (the first centre), no minimum.  grid (blocks, trials)
+__global__ __launch_bounds__(256) void kpp_dist_kernel(const double* __restrict__ X, int n, int d, const double* __restrict__ xsq,
+                                                       const KppState* __restrict__ st, const double* __restrict__ prev, int first_id,
+                                                       double* __restrict__ out, double* __restrict__ partial, int nblocks) {
+  __shared__ double sc[64];
+  __shared__ double sred[4];
+  const int l = blockIdx.y;
+  const int cand = prev ? st->cand[l] : first_id;
+  const double* closest = prev ? prev + (int64_t)st->best * n : nullptr;
+  if (threadIdx.x < d) sc[threadIdx.x] = X[(int64_t)cand * d + threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (i < n) {
+    const double* xi = X + (int64_t)i * d;
+    double dot = 0.0;
+    for (int k = 0; k < d; ++k) dot = __builtin_fma(sc[k], xi[k], dot);
+    {
+#pragma clang fp contract(off)
+      double t = -2.0 * dot;
+      t = t + xsq[cand];
+      t = t + xsq[i];
+      v = t > 0.0 ? t : 0.0;
+    }
+    if (closest) v = closest[i] < v ? closest[i] : v;
+    out[(int64_t)l * n + i] = v;
+  }
+  double s = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)l * nblocks + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// prev_trials candidates of the previous centre (buffers prev[l][n], partial sums) -> the chosen one (indices_out[c - 1]); then,
+// if uniforms != nullptr, the `trials` candidates of the next centre into st_out
+__global__ __launch_bounds__(256) void kpp_select_kernel(int n, const double* __restrict__ prev, const double* __restrict__ partial, int nblocks,
+                                                         int prev_trials, const KppState* __restrict__ st_in, int first_id, KppState* __restrict__ st_out,
+                                                         const double* __restrict__ uniforms, int trials, long long* __restrict__ index_out) {
+  __shared__ double spot[KPP_MAX_TRIALS];
+  __shared__ double schunk[256];
+  __shared__ int sbest;
+  const int tid = threadIdx.x;
+  if (tid < prev_trials) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)tid * nblocks + b];
+    spot[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = 0;
+    for (int l = 1; l < prev_trials; ++l)
+      if (spot[l] < spot[best]) best = l;
+    sbest = best;
+    st_out->best = best;
+    st_out->pot = spot[best];
+    *index_out = st_in ? st_in->cand[best] : first_id;
+  }
+  __syncthreads();
+  if (!uniforms) return;
+  const double* closest = prev + (int64_t)sbest * n;
+  const double pot = spot[sbest];
+  const int chunk = (n + 255) / 256;
+  {
+    double s = 0.0;
+    const int lo = tid * chunk, hi = min(n, lo + chunk);
+    for (int i = lo; i < hi; ++i) s += closest[i];
+    schunk[tid] = s;
+  }
+  __syncthreads();
+  if (tid < trials) {
+    const double v = uniforms[tid] * pot;
+    double run = 0.0;
+    int c = 0;
+    for (; c < 256; ++c) {  // first chunk whose end reaches v
+      if (run + schunk[c] >= v) break;
+      run += schunk[c];
+    }
+    int idx = n - 1;  // np.clip(candidate_ids, None, n - 1)
+    if (c < 256) {
+      const int lo = c * chunk, hi = min(n, lo + chunk);
+      for (int i = lo; i < hi; ++i) {
+        run += closest[i];
+        if (run >= v) {
+          idx = i;
+          break;
+        }
+      }
+      if (idx == n - 1 && hi < n) idx = hi < n ? hi : n - 1;  // (rounding between the chunk sum and the walk: the next element)
+    }
+    st_out->cand[tid] = idx;
+  }
+}
+
 }  // namespace gprx

@@ -1,11 +1,12 @@
 """K-means inducing-point initialisation -- SURVEY.md section 8(f) row N4, ``/root/reference/gpras/gpr.py:312-315``:
 ``KMeans(n_clusters=M, random_state=0, n_init="auto").fit(x).cluster_centers_``.
 
-What stays on the host is what scikit-learn does once: centring the data, the tolerance, and the k-means++ seeding on
-``RandomState(0)`` (``sklearn.cluster.kmeans_plusplus``, the public form of what ``KMeans`` calls).  The Lloyd iterations --
-where the time goes: 50-400 ms for N = 4096-16384, a third of a default 16-mode sparse fit -- run in ``libgprx.so``
-(``gprx_kmeans_lloyd``) with scikit-learn's stopping rules, and end at its centres (<= 1e-12: the cluster means are summed
-in another order).  If a cluster runs empty scikit-learn relocates it to far points; that rare case is handed back to
+What stays on the host is what scikit-learn does once: centring the data, the tolerance, the squared row norms and the
+``RandomState(0)`` draws of the k-means++ seeding (the first index and ``2 + int(log(M))`` uniforms per centre: they do not
+depend on the data).  The seeding itself (``gprx_kmeans_pp``: candidate distances, running minimum, potentials, the
+cumulative-sum search; round 2 profiled it at 120 of the 125 ms of an N = 16384 initialisation when it ran on the host through
+``sklearn.cluster.kmeans_plusplus``) and the Lloyd iterations (``gprx_kmeans_lloyd``, scikit-learn's stopping rules) run in
+``libgprx.so`` and end at scikit-learn's centres (<= 1e-12: the cluster means are summed in another order).  If a cluster runs empty scikit-learn relocates it to far points; that rare case is handed back to
 scikit-learn itself (the reference's own call), never approximated.
 """
 
@@ -19,6 +20,24 @@ from . import _lib
 from ._lib import as_f64, check, ptr
 
 
+def kmeans_pp_indices(xc, n_clusters: int, device: int = 0):
+    """Rows of the (centred) data that ``sklearn.cluster.kmeans_plusplus(xc, n_clusters, random_state=0)`` picks, computed by
+    ``gprx_kmeans_pp``.  The draws are made here exactly as ``_kmeans_plusplus`` makes them: ``choice(n, p=uniform)`` for the first
+    centre, then ``uniform(size=n_local_trials)`` once per further centre."""
+    from sklearn.utils.extmath import row_norms
+
+    n, _ = xc.shape
+    rs = np.random.RandomState(0)
+    trials = 2 + int(np.log(n_clusters))
+    weight = np.ones(n, dtype=xc.dtype)
+    first = int(rs.choice(n, p=weight / weight.sum()))
+    uniforms = np.ascontiguousarray(np.stack([rs.uniform(size=trials) for _ in range(n_clusters - 1)]) if n_clusters > 1 else np.zeros((1, trials)))
+    xsq = np.ascontiguousarray(row_norms(xc, squared=True), dtype=np.float64)
+    indices = np.empty(n_clusters, dtype=np.int64)
+    check(_lib.load().gprx_kmeans_pp(device, ptr(xc), n, xc.shape[1], ptr(xsq), int(n_clusters), trials, first, ptr(uniforms), ptr(indices)))
+    return indices
+
+
 def kmeans_centers(x, n_clusters: int, device: int = 0, return_info: bool = False):
     from sklearn.cluster import kmeans_plusplus
     from sklearn.utils.extmath import row_norms
@@ -30,7 +49,12 @@ def kmeans_centers(x, n_clusters: int, device: int = 0, return_info: bool = Fals
     tol = float(np.mean(np.var(x, axis=0)) * 1e-4)  # sklearn.cluster._kmeans._tolerance
     info = {"device": False, "n_iter": None, "labels": None}
     if d <= 64 and 0 < n_clusters <= n:
-        init, _ = kmeans_plusplus(xc, n_clusters, x_squared_norms=row_norms(xc, squared=True), random_state=0)
+        trials = 2 + int(np.log(n_clusters))  # _kmeans_plusplus: n_local_trials
+        if trials <= 16:
+            indices = kmeans_pp_indices(xc, n_clusters, device)
+            init = xc[indices]
+        else:  # (more than e^14 clusters)
+            init, _ = kmeans_plusplus(xc, n_clusters, x_squared_norms=row_norms(xc, squared=True), random_state=0)
         centers = np.ascontiguousarray(init, dtype=np.float64)
         labels = np.empty(n, dtype=np.int32)
         n_iter, empty = C.c_int(), C.c_int()

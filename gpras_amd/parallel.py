@@ -26,21 +26,55 @@ def shard_units(n_units: int, rank: int, world: int) -> list[int]:
     return [u for u in range(n_units) if u % world == rank]
 
 
-def _dist():
-    import torch.distributed as dist
+def _torch_group():
+    """The initialised torch.distributed module, or None (torch is only imported if the caller already did)."""
+    import sys
 
-    if not dist.is_available() or not dist.is_initialized():
+    tdist = sys.modules.get("torch.distributed")
+    if tdist is not None and tdist.is_available() and tdist.is_initialized():
+        return tdist
+    return None
+
+
+def _dist():
+    dist = _torch_group()
+    if dist is None:
         raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
     return dist
 
 
-_COMM = None  # this process's gprx communicator (RCCL), created on first use when the process group's backend is "nccl"
+def rank_and_world() -> tuple[int, int, str]:
+    """(rank, world, launcher): from the torch.distributed process group when the caller initialised one ("torch"), else from
+    the launcher's environment -- RANK / WORLD_SIZE as set by ``torch.distributed.run`` or any other per-GPU launcher -- with NO
+    torch in the process ("env": the collective then runs over gprx_comm_*, bootstrapped through files)."""
+    import os
+
+    dist = _torch_group()
+    if dist is not None:
+        return dist.get_rank(), dist.get_world_size(), "torch"
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), "env"
+    raise RuntimeError("no torch.distributed process group and no RANK / WORLD_SIZE in the environment: launch one process per GPU")
+
+
+_COMM = None  # this process's gprx communicator (RCCL), created on first use (process group with backend "nccl", or torch-free launch)
 
 
 def communicator(device: int | None = None):
-    """The RCCL communicator behind the C ABI (``gprx_comm_*``), bootstrapped through the process group (the 128-byte id
-    is broadcast from rank 0); ``None`` for CPU process groups (gloo: tests of the host logic)."""
+    """The RCCL communicator behind the C ABI (``gprx_comm_*``).  With a torch.distributed process group the 128-byte id is
+    broadcast through it (``None`` for CPU groups -- gloo: tests of the host logic); in a torch-free launch it travels through
+    files (``gpras_amd.comm.file_rendezvous``), every rank first confirming that it can load RCCL."""
     global _COMM
+    rank, world, launcher = rank_and_world()
+    if launcher == "env":
+        if _COMM is None:
+            import os
+
+            from .comm import Communicator, default_id_prefix
+
+            dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+            _COMM = Communicator.bootstrap(dev, rank, world, id_file=default_id_prefix())
+        return _COMM
     dist = _dist()
     if dist.get_backend() != "nccl":
         return None
@@ -75,7 +109,7 @@ def _all_gather_array(arr: np.ndarray) -> list[np.ndarray]:
         return comm.all_gather(arr)
     import torch
 
-    dist = _dist()
+    dist = _dist()  # (CPU process group: the gloo tests of the host logic)
     device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(device)
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
@@ -91,12 +125,14 @@ class ShardedGPRAS(GPRAS):
     """
 
     def __init__(self, kernel, device: int | None = None) -> None:
-        dist = _dist()
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
+        self.rank, self.world, launcher = rank_and_world()
         if device is None:
             device = 0
-            if dist.get_backend() == "nccl":
+            if launcher == "env":
+                import os
+
+                device = int(os.environ.get("LOCAL_RANK", "0"))
+            elif _dist().get_backend() == "nccl":
                 import torch
 
                 device = torch.cuda.current_device()
@@ -181,37 +217,44 @@ class ShardedGPRAS(GPRAS):
         from ._lib import DeviceBuffer, check, load, ptr
 
         eng, ns = self.engine, x.shape[0]
-        dxs = DeviceBuffer.from_array(x, self.device)
         block = 2 * n_max * ns
-        local = DeviceBuffer(8 * block, self.device)
-        if len(mine) < n_max:  # the padding row of a ragged shard: defined values
-            zeros = np.zeros(ns)
-            for stat in range(2):
-                for row in range(len(mine), n_max):
-                    check(load().gprx_memcpy_h2d(self.device, local.at((stat * n_max + row) * ns), ptr(zeros), zeros.nbytes))
-        chunk = eng.max_cells(want_grad=False)
-        for lo in range(0, len(mine), chunk):
-            part = mine[lo : lo + chunk]
-            _, ok = eng.factorize_batch([self.models[u].unit for u in part], np.stack([self.models[u].theta() for u in part]), 0)
-            if not ok.all():
-                raise RuntimeError(f"kernel matrix not positive definite for mode(s) {[part[i] for i in np.flatnonzero(~ok)]}")
-            for slot, u in enumerate(part):
-                row = lo + slot
-                eng.select_slot(slot)
-                eng.predict_dev(dxs, ns, local.at(row * ns), local.at((n_max + row) * ns), include_noise=True, wait=False)
-        eng.synchronize()  # the predictions are complete before the communicator's stream reads them
-        gather_to_all = root is None
-        recv = DeviceBuffer(8 * block * self.world, self.device) if gather_to_all or root == self.rank else None
-        if gather_to_all:
-            comm.all_gather_dev(local, recv, block)
-        else:
-            comm.gather_dev(local, recv, block, root)
-        comm.synchronize()
-        out = None
-        if recv is not None:
-            gathered = recv.to_array((self.world, 2, n_max, ns))
-            out = self._unpack_predictions([gathered[r] for r in range(self.world)], ns)
-            recv.free()
-        dxs.free()
-        local.free()
-        return out
+        bufs: list = []
+
+        def alloc(buf):
+            bufs.append(buf)
+            return buf
+
+        try:
+            dxs = alloc(DeviceBuffer.from_array(x, self.device))
+            local = alloc(DeviceBuffer(8 * block, self.device))
+            if len(mine) < n_max:  # the padding row of a ragged shard: defined values
+                zeros = np.zeros(ns)
+                for stat in range(2):
+                    for row in range(len(mine), n_max):
+                        check(load().gprx_memcpy_h2d(self.device, local.at((stat * n_max + row) * ns), ptr(zeros), zeros.nbytes))
+            chunk = eng.max_cells(want_grad=False)
+            for lo in range(0, len(mine), chunk):
+                part = mine[lo : lo + chunk]
+                _, ok = eng.factorize_batch([self.models[u].unit for u in part], np.stack([self.models[u].theta() for u in part]), 0)
+                if not ok.all():
+                    raise RuntimeError(f"kernel matrix not positive definite for mode(s) {[part[i] for i in np.flatnonzero(~ok)]}")
+                for slot, u in enumerate(part):
+                    row = lo + slot
+                    eng.select_slot(slot)
+                    eng.predict_dev(dxs, ns, local.at(row * ns), local.at((n_max + row) * ns), include_noise=True, wait=False)
+            eng.synchronize()  # the predictions are complete before the communicator's stream reads them
+            gather_to_all = root is None
+            recv = alloc(DeviceBuffer(8 * block * self.world, self.device)) if gather_to_all or root == self.rank else None
+            if gather_to_all:
+                comm.all_gather_dev(local, recv, block)
+            else:
+                comm.gather_dev(local, recv, block, root)
+            comm.synchronize()
+            out = None
+            if recv is not None:
+                gathered = recv.to_array((self.world, 2, n_max, ns))
+                out = self._unpack_predictions([gathered[r] for r in range(self.world)], ns)
+            return out
+        finally:  # (also when a factorisation raises: no device buffer outlives the call)
+            for buf in bufs:
+                buf.free()

@@ -188,6 +188,10 @@ int gprx_cell_bytes(gprx_handle h, int with_gradient, int64_t* bytes);
  *   gprx_comm_all_gather_host: the same all-gather for small HOST buffers (fitted parameters), staged through the device;
  *                         synchronous.   gprx_comm_barrier: all ranks have arrived (one-element all-reduce + wait). */
 #define GPRX_UNIQUE_ID_BYTES 128
+/* Everything gprx_comm_init needs short of the collective itself: the device is selectable, HIP is initialised, RCCL is loaded
+ * and its symbols resolve.  Ranks agree on this through their launcher BEFORE anyone calls gprx_comm_init (a rank that fails
+ * here would otherwise leave the others blocked inside ncclCommInitRank). */
+int gprx_comm_runtime_check(int device);
 int gprx_comm_unique_id(unsigned char* id128);
 int gprx_comm_init(int device, int rank, int world, const unsigned char* id128, gprx_comm* out);
 int gprx_comm_destroy(gprx_comm c);
@@ -311,6 +315,13 @@ int gprx_metrics_dev(int device, const double* x_dev, const double* y_dev, const
  * Stops like scikit-learn: labels repeat (strict convergence) or sum of squared centre shifts <= tol, at most max_iter.
  * *empty = 1 when a cluster lost all members (scikit-learn relocates it; centres / labels are then undefined and the
  * caller falls back to scikit-learn).  d <= 64. */
+/* k-means++ seeding of the same KMeans call on the device (sklearn.cluster._kmeans._kmeans_plusplus behind gpr.py:313).  The host
+ * keeps the RandomState(0) draws, which do not depend on the data: first_id = random_state.choice(n), uniforms = (m - 1) x trials
+ * values of random_state.uniform(size=trials) with trials = 2 + int(log(m)).  x: (n, d) host, already centred; xsq: its squared row
+ * norms (sklearn.utils.extmath.row_norms).  indices_out: the m chosen rows of x.  Candidate distances, the running minimum, the
+ * potentials and the cumulative-sum search run on the device. */
+int gprx_kmeans_pp(int device, const double* x, int64_t n, int d, const double* xsq, int m, int trials, int64_t first_id, const double* uniforms,
+                   int64_t* indices_out);
 int gprx_kmeans_lloyd(int device, const double* x, int64_t n, int d, double* centers, int m, double tol, int max_iter, int32_t* labels,
                       int* n_iter, int* empty);
 

@@ -92,5 +92,60 @@ def test_two_ranks_over_rccl(lib):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs = [subprocess.Popen([sys.executable, script, str(r), "2", os.path.join(tmp, "rccl.id")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
                  for r in range(2)]
-        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=300)[0].decode())
+        finally:
+            for p in procs:  # a rank that is still alive holds the GPU: end exactly the processes started here
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
         assert all(p.returncode == 0 for p in procs), outs
+
+
+ONE_RUNTIME = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from gpras_amd.comm import Communicator
+comm = Communicator.bootstrap(0, rank=0, world=1)
+(got,) = comm.all_gather(np.arange(5.0))
+comm.barrier()
+libs = sorted({{ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln or "librccl" in ln}})
+comm.close()
+print(json.dumps({{"libs": libs, "torch_imported": "torch" in sys.modules, "ok": bool(np.array_equal(got, np.arange(5.0)))}}))
+"""
+
+
+def test_one_hip_runtime_and_one_rccl_per_rank():
+    """a rank of the torch-free launch maps exactly ONE libamdhip64 and ONE librccl (round 2 mixed torch's
+    own ROCm tree with /opt/rocm's and failed in ncclCommInitRank)."""
+    import json
+
+    res = subprocess.run([sys.executable, "-c", ONE_RUNTIME.format(root=ROOT)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPRX_COMM_DEBUG="1"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["ok"] and not info["torch_imported"]
+    hip = [p for p in info["libs"] if "libamdhip64" in p]
+    rccl = [p for p in info["libs"] if "librccl" in p]
+    assert len(hip) == 1 and len(rccl) == 1, info["libs"]
+    assert os.path.dirname(hip[0]) == os.path.dirname(rccl[0])  # one ROCm tree
+
+
+def test_bench_line_of_a_launched_world_of_one():
+    """bench.py as a launched rank (RANK / WORLD_SIZE in the environment, as torch.distributed.run sets them): torch-free, the
+    collective is gprx_comm_all_gather, one JSON line on stdout."""
+    import json
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cells", "8", "--no-extras",
+                          "--batched-only"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "roofline" in out
+    assert "gprx_comm_all_gather" in out["config"]["collective"] and out["config"]["launcher"].startswith("torch-free")
+    assert len([p for p in out["config"]["hip_and_rccl_libraries_mapped"] if "libamdhip64" in p]) == 1

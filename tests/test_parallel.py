@@ -41,3 +41,66 @@ def test_two_rank_gloo_matches_single_process(tmp_path, monkeypatch):
     mean, var = g.predict(xs)
     assert np.allclose(r0["mean"], mean, rtol=1e-12, atol=1e-14) and np.allclose(r0["var"], var, rtol=1e-12)
     assert np.allclose(r0["z"], np.stack([m.Z for m in g.models]), rtol=1e-12, atol=1e-14)
+
+
+# ---- torch-free rendezvous of the ranks (gpras_amd.comm.file_rendezvous: bench.py --gpus N and ShardedGPRAS without torch) ----
+def _rdv_worker(prefix, rank, world, status, q):
+    from gpras_amd.comm import file_rendezvous
+
+    try:
+        uid = file_rendezvous(prefix, rank, world, status, lambda: bytes(range(128)) + b"\n tail with a newline", timeout_s=20.0)
+        q.put((rank, "id", uid))
+    except Exception as exc:  # noqa: BLE001
+        q.put((rank, type(exc).__name__, str(exc)))
+
+
+def _run_rendezvous(prefix, statuses):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdv_worker, args=(prefix, r, len(statuses), st, q)) for r, st in enumerate(statuses)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    return out
+
+
+def test_file_rendezvous_two_ranks_get_rank0s_id(tmp_path):
+    out = _run_rendezvous(str(tmp_path / "rccl"), ["ok", "ok", "ok"])
+    want = bytes(range(128)) + b"\n tail with a newline"  # arbitrary bytes, newlines included, arrive unchanged
+    assert [(r, kind) for r, kind, _ in out] == [(0, "id"), (1, "id"), (2, "id")]
+    assert all(payload == want for _, _, payload in out)
+
+
+def test_file_rendezvous_one_failing_rank_stops_every_rank(tmp_path):
+    """A rank that cannot load RCCL reports it; NO rank goes on to the collective initialisation (they would block there)."""
+    out = _run_rendezvous(str(tmp_path / "rccl"), ["ok", "rank 1: cannot load RCCL (librccl.so.1)"])
+    assert [(r, kind) for r, kind, _ in out] == [(0, "RuntimeError"), (1, "RuntimeError")]
+    assert all("cannot load RCCL" in msg for _, _, msg in out)
+    assert not os.path.exists(str(tmp_path / "rccl") + ".id")  # rank 0 never created an id
+
+
+def test_file_rendezvous_ignores_stale_files_and_times_out_alone(tmp_path):
+    from gpras_amd.comm import file_rendezvous
+
+    import pytest
+
+    prefix = str(tmp_path / "rccl")
+    with open(prefix + ".ready.1", "wb") as f:  # leftover of a launch 2 hours ago
+        f.write(b"%r\nok" % (__import__("time").time() - 7200.0))
+    with pytest.raises(TimeoutError):
+        file_rendezvous(prefix, 0, 2, "ok", lambda: b"x" * 128, timeout_s=0.5)
+
+
+def test_default_id_prefix_is_shared_by_siblings(monkeypatch):
+    from gpras_amd.comm import default_id_prefix
+
+    monkeypatch.delenv("GPRX_ID_FILE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29123")
+    a = default_id_prefix()
+    assert "29123" in a and str(os.getppid()) in a
+    monkeypatch.setenv("GPRX_ID_FILE", "/tmp/explicit")
+    assert default_id_prefix() == "/tmp/explicit"
