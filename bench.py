@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 MAIN_KERNEL = "gemm_f64_kernel<0,1,64,64,0,0,1>"
-PMC_FILE = "r02_pmc_hbm_traffic.json"
+PMC_FILE = "r03_pmc_hbm_traffic.json"
 
 
 def pmc_traffic(kernel):
@@ -433,6 +433,27 @@ def main():
                 check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
             sizes["N1024_d8_batched_fits_per_s"] = 10 * c1 / (time.perf_counter() - t1)
             sizes["N1024_d8_cells_per_launch"] = c1
+            sizes["N1024_d8_batched_tflops"] = sizes["N1024_d8_batched_fits_per_s"] * 1024**3 / 3 / 1e12
+
+            def roofline_block(handle, run, label):
+                """the main update kernel's launches of one instrumented pass (HIP events around every launch, as the headline block)"""
+                check(lib.gprx_set_profiling(handle, 1), handle)
+                run()
+                pr = (C.c_double * 8)()
+                lib.gprx_last_profile(handle, pr)
+                check(lib.gprx_set_profiling(handle, 0), handle)
+                g_ms, g_n, g_fl = pr[0], pr[1], pr[2]
+                if g_n <= 0 or g_ms <= 0:
+                    return {"kernel": label, "note": "no launch of the main update kernel at this size"}
+                ach = g_fl / (g_ms * 1e-3) / 1e12
+                return {"kernel": label, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                        "launches": g_n, "avg_launch_us": 1e3 * g_ms / g_n, "algorithmic_flops_per_launch": g_fl / g_n,
+                        "panel_launches": pr[4], "panel_avg_launch_us": 1e3 * pr[3] / max(pr[4], 1.0),
+                        "short_k_launches": pr[6], "short_k_tflops": (pr[7] / (pr[5] * 1e-3) / 1e12) if pr[5] > 0 else None}
+
+            sizes["N1024_d8_roofline"] = roofline_block(
+                h1, lambda: check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1),
+                "gemm_f64_kernel<0,1,64,64,0,0,1>: the K = 256 / 512 in-block updates, 512 cells per launch (the whole matrix is one outer block)")
             check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
             t1 = time.perf_counter()
             for _ in range(10):
@@ -457,7 +478,49 @@ def main():
             sizes["N16384_d12_cholesky_tflops"] = n5**3 / 3 / (ms5[1] * 1e-3) / 1e12
             sizes["N16384_d12_cholesky_frac_of_fp64_mfma_peak"] = sizes["N16384_d12_cholesky_tflops"] / FP64_MFMA_PEAK_TFLOPS
             sizes["N16384_d12_kernel_build_GBps"] = (8.0 * n5 * (n5 + 64) / 2 + 8.0 * n5 * d5) / (ms5[0] * 1e-3) / 1e9
+            sizes["N16384_d12_roofline"] = roofline_block(
+                h5, lambda: check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5),
+                "gemm_f64_kernel<0,1,64,64,0,0,1>: bulk HEAD / TAIL updates with K = 512 and the in-block updates with K >= 256 of ONE matrix")
             lib.gprx_destroy(h5)
+            # small matrices in many cells: one workgroup per cell (potrf_cell.h, the default from 256 cells of N <= 512)
+            c6 = 512
+            x6, y6, _ = make_regression(512, DIM, n_outputs=c6, n_test=0, config=2, unit=600)
+            units6 = np.arange(c6, dtype=np.int32)
+            thetas6 = np.ascontiguousarray(np.tile(thetas, (c6 // cells + 1, 1))[:c6])
+            losses6, status6 = np.zeros(c6), np.zeros(c6, dtype=np.int32)
+            for key, knob in (("launch_sequence", -1), ("one_workgroup_per_cell", 1)):
+                check(lib.gprx_set_tuning(b"cell_kernel", knob))
+                h6 = C.c_void_p()
+                check(lib.gprx_create(device, 512, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h6)))
+                check(lib.gprx_set_data(h6, ptr(x6), ptr(y6), c6), h6)
+                for _ in range(2):
+                    check(lib.gprx_factorize_batch(h6, c6, ptr(units6), ptr(thetas6), mask, ptr(losses6), ptr(status6)), h6)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    check(lib.gprx_factorize_batch(h6, c6, ptr(units6), ptr(thetas6), mask, ptr(losses6), ptr(status6)), h6)
+                sizes[f"N512_d8_batched_fits_per_s_{key}"] = 10 * c6 / (time.perf_counter() - t1)
+                lib.gprx_destroy(h6)
+            check(lib.gprx_set_tuning(b"cell_kernel", 0))
+            # the opt-in tile-DAG factorisation of a lone matrix (potrf_dag.h), for the record beside single_cell_ms_per_fit
+            h7 = C.c_void_p()
+            check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h7)))
+            check(lib.gprx_set_data(h7, ptr(x), ptr(y[:, :1].copy()), 1), h7)
+            check(lib.gprx_set_handle_tuning(h7, b"dag", 1), h7)
+            for _ in range(3):
+                check(lib.gprx_factorize(h7, 0, ptr(theta), None, mask, C.byref(loss)), h7)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                check(lib.gprx_factorize(h7, 0, ptr(theta), None, mask, C.byref(loss)), h7)
+            sizes["N4096_single_cell_ms_per_fit_tile_dag_opt_in"] = 1e2 * (time.perf_counter() - t1)
+            lib.gprx_destroy(h7)
+            # k-means inducing-point initialisation (seeding + Lloyd iterations on the device), N = 16384, d = 10, M = 50
+            from gpras_amd.kmeans import kmeans_centers
+
+            xk, _, _ = make_regression(16384, 10, n_outputs=1, n_test=0, config=8, unit=16384)
+            kmeans_centers(xk, 50, device=device)
+            t1 = time.perf_counter()
+            kmeans_centers(xk, 50, device=device)
+            sizes["kmeans_init_N16384_d10_M50_ms"] = 1e3 * (time.perf_counter() - t1)
             extra["other_sizes"] = sizes
             # N1: EOF projection either side of the GP path, device-resident: transform (T, cells) -> (T, k)
             # and reverse (T, k) -> mean + variance fields (T, cells); HBM-bound, rates against the algorithmic bytes

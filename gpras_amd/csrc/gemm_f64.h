@@ -53,6 +53,10 @@ struct GemmArgs {
   // in a fixed order).  The predictive variance needs only these sums of V^T = Ks^T L^-T, never V itself.
   double* rowsq = nullptr;
   int64_t rowsq_ld = 0;
+  // 1: batch entry (cell) -> XCD affinity: workgroups are dealt round-robin over the 8 XCDs in linear order, so linear id L goes to
+  // XCD L % 8; XCD x then walks the cells x, x + 8, ... one after the other, all tiles of a cell on it (its operand panels live in
+  // ONE L2 instead of eight).  Placement is a speed matter only: any mapping computes the same tiles.
+  int cell_xcd = 0;
 };
 
 #ifndef GPRX_GEMM_PFC_DEFAULT
@@ -151,7 +155,14 @@ struct GemmSmem {
 // One output tile: workgroup (bx, by, bz) of the launch grid described in launch_gemm_t.  `smem` is the kernel's single
 // shared array (GemmSmem::doubles).
 template <int TA, int TB, int BM, int BN, int PF, int AXF, int DMA>
-__device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx, const int by, const int bz, double* __restrict__ smem) {
+__device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int by_in, const int bz, double* __restrict__ smem) {
+  int bx = bx_in, by = by_in;
+  if (p.cell_xcd) {
+    const int L = bx_in + p.nwg * by_in, slot = L >> 3;
+    const int cq = slot / p.nwg;
+    by = (L & 7) + 8 * cq;
+    bx = slot - cq * p.nwg;
+  }
   static_assert(!DMA || (TA == 0 && TB == 1 && AXF == 0), "the LDS-DMA staging exists for the NT form only");
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = GemmSmem<TA, TB, BM, BN>::A_ELEMS;
@@ -182,7 +193,7 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx, const int by
     p.C += (int64_t)entry * p.strideC;
   }
   int bid = bx;
-  if (!(p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER))) {
+  if (!p.cell_xcd && !(p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER))) {
     // (with triangular operands the K range, i.e. the cost, varies along the tile order: keep the
     // hardware's round-robin there, which spreads long and short tiles over all XCDs)
     const int q = p.nwg >> 3, rr = p.nwg & 7, xcd = bid & 7, k = bid >> 3;
@@ -539,6 +550,13 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
     p.nwg = p.tiles_n * (p.tiles_n + 1) / 2 + (p.tiles_m - p.tiles_n) * p.tiles_n;
   } else {
     p.nwg = p.tiles_m * p.tiles_n;
+  }
+  {
+    // default on (GPRX_CELL_XCD=0 restores the per-cell interleave): measured on the batched step at N = 4096, 128 cells -- FETCH /
+    // WRITE traffic of the main update kernel 7.57 -> 6.08 GB per launch, 2092 -> 2113 fits/s; same tiles, same arithmetic
+    static const int cell_xcd = getenv("GPRX_CELL_XCD") ? atoi(getenv("GPRX_CELL_XCD")) : 1;
+    p.cell_xcd = (cell_xcd && p.inner == 0 && nsplit == 1 && batch >= 8 && batch % 8 == 0 && p.persist_slots == 0 &&
+                  !(p.flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER))) ? 1 : 0;
   }
   if constexpr (TA == 0 && TB == 1) {
     // NT form on full tiles (every update of the Cholesky): both operands by LDS-DMA.  With the operands off the register

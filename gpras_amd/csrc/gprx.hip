@@ -103,6 +103,7 @@ struct gprx_ctx {
   std::vector<char> slot_ok;
   double batch_ms = 0.0;  // device time of the last batch (events around the whole batch)
   hipEvent_t bev[2] = {nullptr, nullptr};
+  hipEvent_t stagger_evt = nullptr;
 };
 
 struct gprx_comm_ctx {
@@ -574,7 +575,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
   HIPCHK(h, hipMemcpyAsync(h->cellpar.p, par, sizeof(double) * CELL_PAR * count, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemsetAsync(h->cellres.p, 0, sizeof(double) * CELL_RES * count, st));
   if (h->profiling) h->prof.reset();
-  auto enqueue_group = [&](hipStream_t gs, int c0, int cnt) -> int {
+  auto enqueue_group = [&](hipStream_t gs, int c0, int cnt, hipEvent_t wait_evt = nullptr, hipEvent_t record_evt = nullptr) -> int {
     double* K0 = h->arena.p + (int64_t)c0 * cs;
     const double* cpar = h->cellpar.p + (int64_t)c0 * CELL_PAR;
     double* cres = h->cellres.p + (int64_t)c0 * CELL_RES;
@@ -585,12 +586,13 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
+    if (wait_evt) HIPCHK(h, hipStreamWaitEvent(gs, wait_evt, 0));
     if (use_cell_kernel(h->tune, np, cnt) && !h->profiling) {
       // small matrices in many cells: one workgroup owns one cell from the first column to the last (potrf_cell.h)
       HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES));
     } else {
       HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
-                            2 * CELL_RES, &h->tune));
+                            2 * CELL_RES, &h->tune, 0, record_evt));
     }
     const double* beta = K0 + (int64_t)np * ld;
     hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
@@ -605,8 +607,12 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     hipStream_t aux = h->pstreams.aux;
     HIPCHK(h, hipEventRecord(h->pstreams.block_done, st));  // parameter table and cleared results are on the main stream
     HIPCHK(h, hipStreamWaitEvent(aux, h->pstreams.block_done, 0));
-    if ((rc = enqueue_group(st, 0, first))) return rc;
-    if ((rc = enqueue_group(aux, first, count - first))) return rc;
+    // GPRX_BATCH_STAGGER=1: the second group's factorisation waits until the first group has left its first in-block phase, so the
+    // HBM-bound in-block kernels of one group run beside the MFMA-bound bulk updates of the other
+    static const bool stagger = getenv("GPRX_BATCH_STAGGER") && atoi(getenv("GPRX_BATCH_STAGGER")) > 0;
+    if (stagger && !h->stagger_evt) HIPCHK(h, hipEventCreateWithFlags(&h->stagger_evt, hipEventDisableTiming));
+    if ((rc = enqueue_group(st, 0, first, nullptr, stagger ? h->stagger_evt : nullptr))) return rc;
+    if ((rc = enqueue_group(aux, first, count - first, stagger ? h->stagger_evt : nullptr, nullptr))) return rc;
     HIPCHK(h, hipEventRecord(h->pstreams.tail_done, aux));
     HIPCHK(h, hipStreamWaitEvent(st, h->pstreams.tail_done, 0));
   }
@@ -1420,6 +1426,7 @@ int gprx_destroy(gprx_handle h) {
   if (h->spin) hipHostFree(h->spin);
   for (auto& ev : h->bev)
     if (ev) hipEventDestroy(ev);
+  if (h->stagger_evt) hipEventDestroy(h->stagger_evt);
   if (h->info) hipFree(h->info);
   if (h->pin) hipHostFree(h->pin);
   if (h->gparams) hipFree(h->gparams);

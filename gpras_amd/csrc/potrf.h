@@ -204,6 +204,12 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
   constexpr int PWG_ROWS = PanelGeom<RT>::kWgRows;
   constexpr int PANEL_ROWS = PanelGeom<RT>::kOwnRows;
   constexpr int WROWS = 16 * RT;
+#ifndef GPRX_PANEL_NO_SETPRIO
+  // the panel is the dependent chain: its waves outrank the bulk update's waves they share SIMDs with (instruction issue is
+  // arbitrated by priority, then age -- MI355X_MICROARCH.md, two waves per SIMD).  Measured: N = 16384 29.79 -> 29.46 ms,
+  // N = 8192 6.46 -> 6.30 ms, N = 4096 2.17 -> 2.15 ms (tools/setprio_probe.sh): small, consistent, free.
+  __builtin_amdgcn_s_setprio(3);
+#endif
   {
     // batched: blockIdx.y = cell; every per-cell pointer lives in one cell block, `cs` doubles apart
     const int64_t off = (int64_t)blockIdx.y * cs;
@@ -1017,7 +1023,7 @@ struct PotrfStreams {
 // info words info_stride ints apart; every launch carries the cell index in blockIdx.y.
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
                               double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr, int batch = 1, int64_t cs = 0,
-                              int info_stride = 0, const PotrfTuning* tune_in = nullptr, int col_base = 0) {
+                              int info_stride = 0, const PotrfTuning* tune_in = nullptr, int col_base = 0, hipEvent_t first_block_evt = nullptr) {
   const double* prev_stage = nullptr;
   double* prev_dst = nullptr;
   int prev_pw = 0;
@@ -1168,6 +1174,8 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       factor_range(factor_range, C, w);
     }
     if (err != hipSuccess) return err;
+    // (phase-staggered cell groups: another group's stream starts its factorisation when this one leaves its first in-block phase)
+    if (C == 0 && first_block_evt) hipEventRecord(first_block_evt, st);
     const int R = C + w;  // first column right of this block
     if (R >= np) break;
     const int wn = (np - R < ob) ? np - R : ob;     // width of the next block

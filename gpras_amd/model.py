@@ -96,10 +96,19 @@ class GPModel:
     def multiple_assign(self, params):
         """``gpflow.utilities.multiple_assign`` (gpr.py:383)."""
         self.assign(params[".kernel.variance"], params[".kernel.lengthscales"], params[".likelihood.variance"])
+        # ".unconstrained" (extension) only short-cuts the softplus round trip of the values just assigned: it is taken when its
+        # forward transform reproduces them (to a few ulp), so a dictionary whose constrained entries were edited -- the
+        # reference's parameter_dict -> modify -> multiple_assign workflow -- loads the edited values, as gpflow would
         w = params.get(".unconstrained")
         if w is not None and np.size(w) == 2 + self.w_len.size:
             w = np.asarray(w, dtype=np.float64)
+            keep = (self.w_var, self.w_len.copy(), self.w_noise)
+            want = (self.variance, np.array(self.lengthscales, dtype=np.float64), self.noise)
             self.w_var, self.w_len, self.w_noise = float(w[0]), w[1:-1].copy(), float(w[-1])
+            got = (self.variance, np.array(self.lengthscales, dtype=np.float64), self.noise)
+            same = all(np.allclose(g, t, rtol=1e-13, atol=0.0) for g, t in zip(got, want))
+            if not same:
+                self.w_var, self.w_len, self.w_noise = keep
         if ".inducing_variable.Z" in params and self.Z is not None:
             self.Z = params[".inducing_variable.Z"]
 

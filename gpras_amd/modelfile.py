@@ -142,11 +142,28 @@ class _Record:
         self.items.append((key, value))
 
 
+# the only real classes / functions a model pickle may name: numpy's array reconstruction, plain containers, functools.partial
+# (TensorFlow pickles a variable as partial(ResourceVariable, ...)).  Everything else raises -- os.system, builtins.eval and the
+# like never resolve, so loading a file cannot run code of the file's choosing.
+_ALLOWED_GLOBALS = {
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float64"), ("numpy", "int64"), ("numpy", "bool_"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    ("collections", "OrderedDict"), ("functools", "partial"),
+    ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "complex"), ("builtins", "str"), ("builtins", "bytes"), ("builtins", "bool"),
+    ("builtins", "slice"), ("builtins", "range"),
+}
+
+
 class _ReferenceUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module.split(".")[0] in _FOREIGN:
             return type(name, (_Record,), {"__module__": module})
-        return super().find_class(module, name)
+        if (module, name) in _ALLOWED_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"global {module}.{name} is not allowed in a model file")
 
 
 def _find_value(obj, depth=0):

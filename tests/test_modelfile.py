@@ -135,3 +135,45 @@ def test_unrecoverable_parameters_fail_with_a_clear_message(tmp_path):
         f.write(b"\x00\x01junk")
     with pytest.raises(ValueError):
         modelfile.load(tmp_path / "junk.bin")
+
+
+def test_pickle_reader_refuses_globals_outside_the_allow_list(tmp_path):
+    """the reader of reference pickles resolves numpy reconstruction, plain containers and functools.partial only --
+    a file that names os.system (or anything else) is refused instead of executed."""
+    import pickle
+
+    import pytest
+
+    class Evil:
+        def __reduce__(self):
+            import os
+
+            return (os.system, ("echo pwned > /dev/null",))
+
+    path = tmp_path / "gpr.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"kernel": "RBF", "models": [Evil()]}, f)
+    with pytest.raises(ValueError, match="not allowed"):
+        modelfile.load(str(path))
+
+
+def test_multiple_assign_prefers_edited_constrained_values():
+    """parameter_dict -> edit -> multiple_assign (the reference's workflow, gpr.py:363, :383): a stale ``.unconstrained`` entry
+    must not override the edited values; an untouched dictionary still reloads bit-identical variables."""
+    import numpy as np
+
+    from gpras_amd.model import GPModel
+
+    class FakeEngine:
+        n_len, d, ard = 1, 3, False
+
+    m = GPModel(FakeEngine(), 0, None, 1.3, 0.7, 0.2)
+    params = m.parameter_dict()
+    w_before = m.theta().copy()
+    m2 = GPModel(FakeEngine(), 0, None, 1.0, 1.0, 1.0)
+    m2.multiple_assign(params)
+    assert np.array_equal(m2.theta(), w_before)  # untouched: the unconstrained variables come back bit for bit
+    params[".kernel.variance"] = np.array(2.5)  # edited, ".unconstrained" left stale
+    m3 = GPModel(FakeEngine(), 0, None, 1.0, 1.0, 1.0)
+    m3.multiple_assign(params)
+    assert abs(m3.variance - 2.5) < 1e-12 and abs(m3.noise - 0.2) < 1e-12
