@@ -150,13 +150,19 @@ def main():
     comm_error = ""
     launcher = "single process"
     if distributed and os.environ.get("GPRX_BENCH_TORCH") != "1":
-        from gpras_amd.comm import Communicator, default_id_prefix
+        from gpras_amd.comm import Communicator, agree, default_id_prefix
 
+        prefix = default_id_prefix()
         try:
-            comm = Communicator.bootstrap(device, rank, world, id_file=default_id_prefix())
+            comm = Communicator.bootstrap(device, rank, world, id_file=prefix)
             launcher = "torch-free ranks: environment + file rendezvous, gprx_comm_* (RCCL behind the C ABI) for barriers, max and the gather"
         except Exception as exc:  # noqa: BLE001
             comm, comm_error = None, f"{type(exc).__name__}: {exc}"
+        if world > 1 and not agree(prefix, "comm", rank, world, comm is not None):
+            # (every rank takes the same branch: one rank without a communicator sends all of them to the torch.distributed path)
+            if comm is not None:
+                comm.close()
+            comm, comm_error = None, comm_error or "another rank could not create its communicator"
     if distributed and comm is None:
         import torch  # noqa: PLC0415
         import torch.distributed as dist  # noqa: PLC0415

@@ -85,6 +85,25 @@ def file_rendezvous(prefix: str, rank: int, world: int, status: str, make_id, ti
     return wait_for(f"{prefix}.id", "the RCCL id of rank 0")
 
 
+def agree(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0) -> bool:
+    """Every rank reports ``ok`` for ``stage`` through files; True only if all ranks said yes (a rank that never reports counts as
+    no after ``timeout_s``).  Used where ranks must take the SAME branch without a working collective (fallback decisions)."""
+    path = f"{prefix}.{stage}."
+    tmp = f"{path}{rank}.tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(b"1" if ok else b"0")
+    os.replace(tmp, f"{path}{rank}")
+    t0, verdict = time.time(), True
+    for r in range(world):
+        while not os.path.exists(f"{path}{r}"):
+            if time.time() - t0 > timeout_s:
+                return False
+            time.sleep(0.02)
+        with open(f"{path}{r}", "rb") as f:
+            verdict = verdict and f.read() == b"1"
+    return verdict
+
+
 def default_id_prefix() -> str:
     """A rendezvous prefix every rank of ONE launch computes identically and no other launch shares: explicit ``GPRX_ID_FILE``, else
     /tmp + the launcher's port + its run id + the launcher's pid (the ranks are siblings: children of one ``torch.distributed.run``
@@ -148,7 +167,13 @@ class Communicator:
             msg = _lib.load().gprx_comm_last_error(None)
             status = f"rank {rank}: {msg.decode() if msg else 'libgprx error ' + str(rc)}"
         uid = file_rendezvous(id_file, rank, world, status, new_unique_id, timeout_s=timeout_s)
-        return cls(device, rank, world, uid)
+        comm = cls(device, rank, world, uid)  # (collective: when it returns, every rank has read the id)
+        for leftover in [f"{id_file}.ready.{rank}"] + ([f"{id_file}.id"] if rank == 0 else []):
+            try:
+                os.remove(leftover)
+            except OSError:
+                pass
+        return comm
 
     # -- lifetime --------------------------------------------------------------------------------------------------
     def close(self):

@@ -580,10 +580,16 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
           return hipGetLastError();
         }
       }
+      // Experiment knob (GPRX_GEMM_PAD_LDS = bytes of unused dynamic LDS for ONE matrix's updates, default 0): caps this kernel at
+      // 3 (9216) or 2 (22000) workgroups per CU, so that a panel workgroup of the chain (200-224 VGPRs per lane; five resident
+      // workgroups of this kernel leave 72 per SIMD) always finds room.  Measured without effect on the panels' 81 us beside the
+      // bulk update at N = 16384 (29.5 / 29.6 / 31.3 ms for 5 / 3 / 2 workgroups per CU): not a residency effect.
+      static const int pad_env = getenv("GPRX_GEMM_PAD_LDS") ? atoi(getenv("GPRX_GEMM_PAD_LDS")) : -1;
+      const unsigned pad = (batch == 1 && BM * BN <= 64 * 64) ? (unsigned)(pad_env >= 0 ? pad_env : 0) : 0u;
       if (prefetch_c)
-        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), pad, st, p);
       else
-        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, BM, BN, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_f64_kernel<0, 1, BM, BN, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), pad, st, p);
       return hipGetLastError();
     }
   }

@@ -2785,6 +2785,13 @@ extern "C" int gprx_dag_stamps(gprx_handle h, unsigned long long* out, int max_w
   return n;
 }
 
+#ifdef GPRX_CHAIN_STAMPS
+extern "C" int gprx_chain_stamps(unsigned long long* out16) {
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(gprx::g_chain_stamps), sizeof(unsigned long long) * 16);
+  return 0;
+}
+#endif
+
 #ifdef GPRX_PANEL_STAMPS
 int gprx_panel_stamps(unsigned long long* out64) {
   hipMemcpyFromSymbol(out64, HIP_SYMBOL(gprx::g_panel_stamps), sizeof(unsigned long long) * 64);
@@ -2804,6 +2811,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
   else if (k == "dag" && value >= -1 && value <= 1) t.dag = value;
   else if (k == "cell_kernel" && value >= -1 && value <= 1) t.cell_kernel = value;
+  else if (k == "split_updates" && value >= 0 && value <= 1) t.split_updates = value;
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
   else return false;
   return true;

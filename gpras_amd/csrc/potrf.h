@@ -962,6 +962,8 @@ struct PotrfTuning {
   int panel_occ = 0;     // 3: panel kernel compiled for 3 workgroups per CU (168 registers, small spills) instead of 2
   int inblock = 0;       // 1: right-looking K = 64 strips inside an outer block instead of the recursive halving
   int split_panel = 0;   // 1: always the split panel (diagonal workgroup + rows kernel), -1: never, 0: from 24 cells per launch on
+  int split_updates = 0; // lone matrix: 1 = look-ahead split of the K >= 256 updates over a side stream (see potrf_lower; measured
+                         // slower: 2.17 -> 2.66 ms at N = 4096), 0 = every update whole on the main stream (default)
   int cell_kernel = 0;   // batched cells: 1 = always one workgroup per cell (potrf_cell.h), -1 never, 0 = for np <= 1024 and >= 256 cells
   int dag = 0;           // lone matrices: 1 = the tile-DAG factorisation (potrf_dag.h); 0 / -1 = the launch-per-panel schedule (default)
 };
@@ -976,6 +978,7 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
     if (const char* e = getenv("GPRX_SPLIT_PANEL")) v.split_panel = atoi(e);
     if (const char* e = getenv("GPRX_DAG")) v.dag = atoi(e);
+    if (const char* e = getenv("GPRX_SPLIT_UPDATES")) v.split_updates = atoi(e);
     if (const char* e = getenv("GPRX_CELL_KERNEL")) v.cell_kernel = atoi(e);
     return v;
   }();
@@ -985,18 +988,34 @@ inline PotrfTuning& potrf_tuning() {
 // Streams and events of the look-ahead schedule (owned by the caller, reused across factorisations).
 struct PotrfStreams {
   hipStream_t aux = nullptr;
+  hipStream_t side = nullptr;  // look-ahead inside a block: the parts of an update that the next panel does not need yet
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
   hipEvent_t block_done = nullptr, tail_done = nullptr;
+  hipEvent_t next_event() {
+    if (used == pool.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
   hipError_t init() {
     hipError_t e = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);  // normal priority (see gprx_create)
     if (e != hipSuccess) return e;
+    if ((e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&block_done, hipEventDisableTiming)) != hipSuccess) return e;
     return hipEventCreateWithFlags(&tail_done, hipEventDisableTiming);
   }
   void destroy() {
     if (aux) hipStreamDestroy(aux);
+    if (side) hipStreamDestroy(side);
+    for (auto e : pool) hipEventDestroy(e);
+    pool.clear();
+    used = 0;
     if (block_done) hipEventDestroy(block_done);
     if (tail_done) hipEventDestroy(tail_done);
-    aux = nullptr;
+    aux = side = nullptr;
     block_done = tail_done = nullptr;
   }
 };
@@ -1068,7 +1087,38 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     const char* c = getenv("GPRX_FUSE_K64");
     return !(a && atoi(a) == 0) && !(b && atoi(b) == 0) && !(c && atoi(c) == 0);
   }();
+  // ---- look-ahead inside and between blocks (ONE matrix on two extra streams) ------------------------------------------------
+  // An update of n > 64 columns with K >= 256 is needed by the NEXT panel only in its first 64 columns; the rest is needed one
+  // panel, three panels, seven panels ... later.  So the update is split by columns: [0, 64) stays on the main stream, the rest
+  // goes to the side stream in dyadic pieces [64,128), [128,256), [256,512), ... each followed by an event; the main stream waits
+  // for a piece only before its first launch that touches those columns.  The chain (panel, fused K = 64 update, panel, ...) no
+  // longer carries the K = 256 / 512 in-block updates (17 / 43 us each at N = 4096) nor the HEAD updates (113 us) whole.  Same
+  // tiles, same K range per tile, same arithmetic: the factor is bit-identical to the unsplit schedule (tested).
+  // OPT-IN ("split_updates" = 1): measured on MI355X it LOSES -- N = 4096 2.17 -> 2.66 ms, N = 8192 6.2 -> 7.0, N = 16384 29.5 ->
+  // 30.5: about 40 cross-stream event edges per factorisation, and every piece that runs beside a panel slows that panel the way
+  // the TAIL update does at N = 16384 (81 us instead of 20).  Capping the update kernel at 3 or 2 workgroups per CU
+  // (GPRX_GEMM_PAD_LDS, so that a 200-224-register panel workgroup always finds room) changes neither number: the slow-down of a
+  // panel beside a bulk update is not a residency effect.
+  struct PendingCols {
+    int begin, end;
+    hipEvent_t ev;
+  };
+  std::vector<PendingCols> pending;
+  const bool split_ok = ps && ps->side && batch == 1 && !prof && tune.split_updates > 0 && tune.inblock != 1;
+  if (split_ok) ps->used = 0;
+  auto main_wait = [&](int a, int b) {  // the main stream is about to touch columns [a, b)
+    for (size_t q = 0; q < pending.size();) {
+      if (pending[q].begin < b && pending[q].end > a) {
+        hipStreamWaitEvent(st, pending[q].ev, 0);
+        pending[q] = pending.back();
+        pending.pop_back();
+      } else {
+        ++q;
+      }
+    }
+  };
   auto panel = [&](int c, int pw, bool fuse = false) {
+    main_wait(c, c + pw);
     const int rows_below = total_rows - c - pw;
     double* Acc = A + (int64_t)c * lda + c;
     if (prof) {
@@ -1132,16 +1182,42 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     if (prof) hipEventRecord(prof->next(), st);
   };
   // in-block update: columns [c1, c1 + n) and every row from c1 down, by the k columns [c0, c0 + k) factored before
-  auto inblock_update = [&](int c0, int k, int c1, int n) {
+  auto update_on = [&](hipStream_t s_, int c0, int k, int c1, int n, int tile) {
     const int rows = total_rows - c1;
     const double* L21 = A + (int64_t)c1 * lda + c0;
     double* A22 = A + (int64_t)c1 * lda + c1;
-    mark_gemm(st, n, rows - n, n, k, k <= 128);  // K <= 128 runs the short-K kernels (syrk_k64 / C-prefetch GEMM), longer K the main GEMM kernel
-    hipError_t e = (k == NB) ? launch_update_k64(st, rows, n, L21, lda, A22, lda, batch, cs)
-                             : launch_gemm(st, 0, 1, rows, n, k, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, 64, batch, cs, cs, cs);
-    mark_end(st);
+    mark_gemm(s_, n, rows - n, n, k, k <= 128);  // K <= 128 runs the short-K kernels (syrk_k64 / C-prefetch GEMM), longer K the main GEMM kernel
+    hipError_t e = (k == NB) ? launch_update_k64(s_, rows, n, L21, lda, A22, lda, batch, cs)
+                             : launch_gemm(s_, 0, 1, rows, n, k, -1.0, L21, lda, L21, lda, 1.0, A22, lda, GEMM_C_LOWER, tile, batch, cs, cs, cs);
+    mark_end(s_);
     if (e != hipSuccess && err == hipSuccess) err = e;
   };
+  // the update as a whole on the main stream, or split (see above): `side_wait` = an event the side stream must see first (the
+  // last writer of these columns on another stream), may be null
+  auto split_update = [&](int c0, int k, int c1, int n, int tile, hipEvent_t side_wait) {
+    if (!split_ok || n <= NB || k < 256) {
+      main_wait(c1, c1 + n);
+      if (side_wait) hipStreamWaitEvent(st, side_wait, 0);
+      update_on(st, c0, k, c1, n, tile);
+      return;
+    }
+    hipEvent_t ready = ps->next_event();  // the k columns [c0, c0 + k) are final on the main stream
+    hipEventRecord(ready, st);
+    hipStreamWaitEvent(ps->side, ready, 0);
+    if (side_wait) hipStreamWaitEvent(ps->side, side_wait, 0);
+    for (int start = NB; start < n;) {  // pieces [64,128), [128,256), [256,512), ...: a piece is as wide as everything left of it
+      const int wdt = n - start < start ? n - start : start;
+      update_on(ps->side, c0, k, c1 + start, wdt, tile);
+      hipEvent_t done = ps->next_event();
+      hipEventRecord(done, ps->side);
+      pending.push_back({c1 + start, c1 + start + wdt, done});  // (older pieces over the same columns stay listed: all are waited for)
+      start += wdt;
+    }
+    main_wait(c1, c1 + NB);
+    if (side_wait) hipStreamWaitEvent(st, side_wait, 0);
+    update_on(st, c0, k, c1, NB, tile);
+  };
+  auto inblock_update = [&](int c0, int k, int c1, int n) { split_update(c0, k, c1, n, 64, nullptr); };
   // Inside an outer block the panels are combined recursively: factor the left half, update the right half with
   // it (K = half the width), factor the right half.  The block's columns are rewritten log2(w / 64) times
   // instead of w / 64 times (a K = 64 update moves 16 bytes of C per 128 flops -- the strips were HBM-bound once
@@ -1180,16 +1256,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     if (R >= np) break;
     const int wn = (np - R < ob) ? np - R : ob;     // width of the next block
     const double* Lpan = A + (int64_t)R * lda + C;  // L[R:, C:C+w]
-    // HEAD(J): columns [R, R + wn), rows [R, total_rows)
-    if (ps && tail_pending) hipStreamWaitEvent(st, ps->tail_done, 0);
-    {
-      const int rows = total_rows - R;
-      mark_gemm(st, wn, rows - wn, wn, w);
-      hipError_t e = launch_gemm(st, 0, 1, rows, wn, w, -1.0, Lpan, lda, Lpan, lda, 1.0, A + (int64_t)R * lda + R, lda, GEMM_C_LOWER,
-                                   batch > 1 ? bulk_tile : 64, batch, cs, cs, cs);
-      mark_end(st);
-      if (e != hipSuccess) return e;
-    }
+    // HEAD(J): columns [R, R + wn), rows [R, total_rows); the last writer of these columns is TAIL(J-1) on the aux stream
+    split_update(C, w, R, wn, batch > 1 ? bulk_tile : 64, (ps && tail_pending) ? ps->tail_done : nullptr);
+    if (err != hipSuccess) return err;
     if (ps) hipEventRecord(ps->block_done, st);
     // TAIL(J): columns [R + wn, np), rows [R + wn, total_rows)
     const int R2 = R + wn;
@@ -1212,6 +1281,7 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
       }
     }
   }
+  main_wait(0, 1 << 30);  // (nothing is left in flight on the side stream)
   // the last panel's diagonal block is still staged
   if (prev_stage) hipLaunchKernelGGL(copy_block_kernel, dim3(batch), dim3(256), 0, st, prev_stage, prev_dst, lda, prev_pw, cs);
   // everything later on `st` must see the aux stream's last update

@@ -152,9 +152,17 @@ struct ChainCtx {
   int bad;
 };
 
+#ifdef GPRX_CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[16];
+#define CSTAMP(i) if constexpr (P == 3) { if (c.tid == 0) g_chain_stamps[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define CSTAMP(i)
+#endif
+
 template <int P>
 __device__ __forceinline__ void chain_step(d4 (&acc)[2][4], ChainCtx& c) {
   constexpr int C0 = 8 * P;
+  CSTAMP(0)
   constexpr int KT = C0 / 16;
   constexpr int HALF = P & 1;
   // accumulators -> LDS (the lanes that hold these 8 columns)
@@ -164,13 +172,16 @@ __device__ __forceinline__ void chain_step(d4 (&acc)[2][4], ChainCtx& c) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) c.sIn[(64 * rt + 16 * c.wave + c.g + 4 * q) * PSUB + (c.r & 7)] = acc[rt][KT][q];
   }
+  CSTAMP(1)
   lds_barrier();
+  CSTAMP(2)
   // every thread factors the 8 x 8 diagonal sub-block (rows C0 .. C0 + 7 of the diagonal block): potrf.h panel_step
   double l[8][8], rinv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int k = 0; k <= j; ++k) l[j][k] = c.sIn[(C0 + j) * PSUB + k];
+  CSTAMP(3)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     double s = l[j][j];
@@ -191,6 +202,7 @@ __device__ __forceinline__ void chain_step(d4 (&acc)[2][4], ChainCtx& c) {
       l[i][j] = t * ri;
     }
   }
+  CSTAMP(4)
   if (c.tid < 128) {
     const int zero_above = c.tid < NB ? c.tid : (1 << 30);
     double x[8];
@@ -204,7 +216,9 @@ __device__ __forceinline__ void chain_step(d4 (&acc)[2][4], ChainCtx& c) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) c.sX[c.tid * PSUB + k] = x[k];
   }
+  CSTAMP(5)
   lds_barrier();
+  CSTAMP(6)
   if constexpr (C0 + 8 < NB) {
     constexpr int KT0 = (C0 + 8) / 16;
     double fa[2][2], fb[4][2];
@@ -226,12 +240,14 @@ __device__ __forceinline__ void chain_step(d4 (&acc)[2][4], ChainCtx& c) {
         acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
       }
   }
+  CSTAMP(7)
   if ((c.r >> 3) == HALF) {  // solved values back into the accumulators
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[rt][KT][q] = c.sX[(64 * rt + 16 * c.wave + c.g + 4 * q) * PSUB + (c.r & 7)];
   }
+  CSTAMP(8)
 }
 
 __device__ __forceinline__ int* dag_ver(const DagArgs& p, int i, int j) { return p.st + dag_ver_off(p.T) + (size_t)i * p.T + j; }

@@ -340,6 +340,8 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
  * "inblock" (1: right-looking K = 64 strips inside an outer block instead of recursive halving), "split_panel"
  * (1: always one diagonal workgroup + a rows-only kernel per panel, -1: never; default: from 24 cells per launch on).
+ * "split_updates" (1: ONE matrix's in-block and HEAD updates with K >= 256 are split by columns -- the 64 columns the next panel
+ * needs on the main stream, the rest in dyadic pieces on a side stream behind events; bit-identical factor, measured slower).
  * "dag" (1: ONE matrix is factored by the tile-DAG kernel -- a single persistent launch, the dependent chain of diagonal
  * blocks in one workgroup, every other tile task claimed from a queue and ordered by per-tile version counters in device memory;
  * deterministic, within rounding of the default; default 0 = the launch-per-panel schedule, which measured faster on MI355X:

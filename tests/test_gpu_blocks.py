@@ -286,3 +286,26 @@ def test_fit_through_the_tile_dag_equals_the_launch_schedule(lib):
         lib.gprx_destroy(h)
     assert abs(res[1][0] - res[0][0]) <= 1e-12 * abs(res[0][0])
     assert rel_err(res[1][1], res[0][1]) < 1e-11 and rel_err(res[1][2], res[0][2]) < 1e-11
+
+
+@pytest.mark.parametrize("n,extra", [(2112, 64), (4096, 64)])
+def test_potrf_lookahead_split_is_bit_identical(lib, n, extra):
+    """"split_updates" = 1 (the K >= 256 updates of a lone matrix split by columns over a side stream, potrf.h): the same tiles
+    with the same K ranges, so the factor, the right-hand-side rows and the inverse blocks equal the default schedule bit for bit."""
+    rng = np.random.default_rng(n + 1)
+    g = rng.standard_normal((n, 96))
+    full = np.vstack([g @ g.T / 96 + np.eye(n), rng.standard_normal((extra, n))])
+    outs = []
+    try:
+        for knob in (0, 1, 1):
+            check(lib.gprx_set_tuning(b"split_updates", knob))
+            dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
+            info = C.c_int(0)
+            check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
+            outs.append((np.tril(dA.to_array((n + extra, n))[:n]), dA.to_array((n + extra, n))[n:], dI.to_array((n // 64, 64, 64))))
+            dA.free()
+            dI.free()
+    finally:
+        lib.gprx_set_tuning(b"split_updates", 0)
+    for other in outs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], other))

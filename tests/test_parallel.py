@@ -104,3 +104,25 @@ def test_default_id_prefix_is_shared_by_siblings(monkeypatch):
     assert "29123" in a and str(os.getppid()) in a
     monkeypatch.setenv("GPRX_ID_FILE", "/tmp/explicit")
     assert default_id_prefix() == "/tmp/explicit"
+
+
+def _agree_worker(prefix, rank, world, ok, q):
+    from gpras_amd.comm import agree
+
+    q.put((rank, agree(prefix, "comm", rank, world, ok, timeout_s=20.0)))
+
+
+def test_agree_is_unanimous(tmp_path):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    for votes, want in (([True, True, True], True), ([True, False, True], False)):
+        prefix = str(tmp_path / f"agree{int(want)}")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_agree_worker, args=(prefix, r, len(votes), v, q)) for r, v in enumerate(votes)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=60) for _ in procs)
+        for p in procs:
+            p.join(timeout=30)
+        assert got == [(r, want) for r in range(len(votes))]
