@@ -28,6 +28,7 @@
 // code instead of hanging the device.  Queue order: every dependency of task t is a chain step or a task before t, and a
 // workgroup only ever waits on those -- so the launch drains whatever the residency (workgroups that never start claim nothing).
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "gemm_f64.h"
@@ -871,10 +872,63 @@ inline std::vector<DagTask> dag_build_tasks(int T, int R) {
   return v;
 }
 
+// "Lazy" schedule (GPRX_DAG_SCHED=1): what the stamps of the eager schedule asked for.  The dependent loop of a row block i --
+// TRSM(i,c) -> update of (i,c+1) by column c -> TRSM(i,c+1) -- stays two SINGLE-tile tasks per column (7 us each, measured);
+// every other update of a tile is aggregated over K:
+//   tile (i,j) with `pend` worker-owned columns (j; j-1 for i = j+1 and j-2 for i = j: the rest belongs to the fused critical task
+//   and the chain):  lazy chunks [8m, 8m+8) while 8m+8 <= B,  one catch-up [B, pend-2),  two prompt singles [pend-2, pend-1),
+//   [pend-1, pend);   B = 8 floor((pend-2)/8) - 8 (>= 0), so a catch-up spans 8..15 column blocks and has two chain steps of slack.
+// Emission (the queue is claimed in order, so this IS the priority): at step k the fused critical task, the TRSMs of column k, the
+// prompt singles ending at k+1, the catch-ups ending at k+1, then the slice of lazy chunks due now (chunk m is spread over the
+// steps 8m+7 .. 8m+14 by tile column: a burst of ~1500 K = 512 tasks in front of the next column's TRSMs would stall every row).
+// Per tile the tasks appear in plan order (a claimed task only ever waits for earlier ones).
+inline std::vector<DagTask> dag_build_tasks_lazy(int T, int R) {
+  constexpr int G = 8;
+  std::vector<std::vector<DagTask>> at(T + 1);  // tasks by emission step, already in intra-step order classes
+  std::vector<std::vector<DagTask>> prompt(T + 1), catchup(T + 1), lazy(T + 1);
+  auto pend_of = [](int i, int j) { return i == j ? j - 2 : (i == j + 1 ? j - 1 : j); };
+  for (int j = 1; j < T; ++j) {
+    // rows of this tile column grouped by plan: i == j, i == j + 1 (their own plans), i >= j + 2 (one plan, panels of rows)
+    auto emit_plan = [&](int i0, int ni, int pend) {
+      if (pend <= 0) return;
+      const int pfirst = pend - 2 > 0 ? pend - 2 : 0;  // prompt singles cover [pfirst, pend)
+      int B = ((pend - 2) / G) * G - G;
+      if (B < 0 || pend - 2 <= 0) B = 0;
+      for (int m = 0; G * m + G <= B; ++m) {
+        int step = G * m + G - 1 + ((j - (G * m + G)) * G) / (T - (G * m + G) > 0 ? T - (G * m + G) : 1);
+        if (step > pend - 4) step = pend - 4;
+        if (step < G * m + G - 1) step = G * m + G - 1;
+        for (int r0 = 0; r0 < ni; r0 += DAG_NI)
+          lazy[step].push_back(DagTask{(uint16_t)(i0 + r0), (uint16_t)(ni - r0 < DAG_NI ? ni - r0 : DAG_NI), (uint16_t)j, (uint16_t)(G * m), (uint16_t)(G * m + G), 0});
+      }
+      if (pfirst > B)
+        for (int r0 = 0; r0 < ni; r0 += DAG_NI)
+          catchup[pfirst - 1].push_back(DagTask{(uint16_t)(i0 + r0), (uint16_t)(ni - r0 < DAG_NI ? ni - r0 : DAG_NI), (uint16_t)j, (uint16_t)B, (uint16_t)pfirst, 0});
+      for (int c = pfirst; c < pend; ++c)
+        for (int r = 0; r < ni; ++r) prompt[c].push_back(DagTask{(uint16_t)(i0 + r), 1, (uint16_t)j, (uint16_t)c, (uint16_t)(c + 1), 0});
+    };
+    emit_plan(j, 1, pend_of(j, j));
+    if (j + 1 < R) emit_plan(j + 1, 1, pend_of(j + 1, j));
+    if (j + 2 < R) emit_plan(j + 2, R - (j + 2), j);
+  }
+  std::vector<DagTask> v;
+  for (int k = 0; k < T; ++k) {
+    if (k + 2 < R) v.push_back(DagTask{(uint16_t)(k + 2), 1, (uint16_t)k, (uint16_t)k, (uint16_t)(k + 1), 1});  // fused (dag_critical)
+    for (int i = k + 3; i < R; ++i) v.push_back(DagTask{(uint16_t)i, 1, (uint16_t)k, (uint16_t)k, (uint16_t)(k + 1), 0});  // TRSMs, singles
+    // prompt singles of this step: the tile column next to the front first (it feeds the next TRSMs)
+    std::stable_sort(prompt[k].begin(), prompt[k].end(), [](const DagTask& a, const DagTask& b) { return a.j < b.j; });
+    v.insert(v.end(), prompt[k].begin(), prompt[k].end());
+    v.insert(v.end(), catchup[k].begin(), catchup[k].end());
+    v.insert(v.end(), lazy[k].begin(), lazy[k].end());
+  }
+  return v;
+}
+
 inline hipError_t dag_ensure_plan(DagPlan& plan, int T, int R, hipStream_t st) {
   if (plan.T == T && plan.R == R) return hipSuccess;
   plan.destroy();
-  const std::vector<DagTask> tasks = dag_build_tasks(T, R);
+  const bool lazy_sched = getenv("GPRX_DAG_SCHED") && atoi(getenv("GPRX_DAG_SCHED")) == 1;
+  const std::vector<DagTask> tasks = lazy_sched ? dag_build_tasks_lazy(T, R) : dag_build_tasks(T, R);
   hipError_t e = hipMalloc((void**)&plan.tasks, sizeof(DagTask) * (tasks.size() + 1));
   if (e != hipSuccess) return e;
   plan.state_bytes = sizeof(int) * dag_state_ints(T, R);
