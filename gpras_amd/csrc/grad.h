@@ -70,21 +70,61 @@ __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_
   const int cp = lane & 31, rsub = lane >> 5;
 
   auto stage = [&](int k0) {
+    // (unconditional loads from clamped indices, selected afterwards: predicated loads each cost a full memory round trip)
+    double ra[2], rb[2];
+    const int kc = min(k0 + (tid & 7), p.d - 1);
+    const double s = p.ls[kc];
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int pt = (tid + 256 * rep) >> 3;
+      ra[rep] = p.a[(int64_t)min(i0 + pt, p.n1 - 1) * p.d + kc];
+      rb[rep] = p.b[(int64_t)min(j0 + pt, p.n2 - 1) * p.d + kc];
+    }
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int q = tid + 256 * rep;
       const int pt = q >> 3, kk = q & 7;
-      const int k = k0 + kk;
-      double va = 0.0, vb = 0.0;
-      if (k < p.d) {
-        const double s = p.ls[k];
-        if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] / s;
-        if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] / s;
+      const bool live = k0 + kk < p.d;
+      double va, vb;
+      if constexpr (FORM == 0) {  // the scaled coordinates of kmat_kernel's difference form: x * (1 / l)
+        const double inv = 1.0 / s;
+        va = ra[rep] * inv;
+        vb = rb[rep] * inv;
+      } else {
+        va = ra[rep] / s;
+        vb = rb[rep] / s;
       }
-      sA[pt][kk] = va;
-      sBt[kk][pt] = vb;
+      sA[pt][kk] = (live && i0 + pt < p.n1) ? va : 0.0;
+      sBt[kk][pt] = (live && j0 + pt < p.n2) ? vb : 0.0;
     }
   };
+
+  // The weights of this thread's 8 x 2 elements, requested BEFORE the distance pass so that their latency hides under it.
+  // Every load is unconditional (indices clamped into the matrix, masks applied afterwards): with the bounds tests around the
+  // loads hipcc emitted a branch and a full wait per load -- 16 serialised memory round trips per workgroup, 12 ms per 128-cell
+  // launch for a kernel whose HBM floor is under 2 ms.  Interior tiles read two neighbouring weights with one 16-byte load.
+  double wraw[8][2], urow[8], vcol[2] = {0.0, 0.0};
+  {
+    const bool wide = i0 + KM_T <= p.n1 && j0 + KM_T <= p.n2 && (p.ldw & 1) == 0 && ((reinterpret_cast<uintptr_t>(p.W) & 15) == 0);
+    const int jc0 = min(j0 + 2 * cp, p.n2 - 1), jc1 = min(j0 + 2 * cp + 1, p.n2 - 1);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ic = min(i0 + wave * 16 + 2 * it + rsub, p.n1 - 1);
+      if (wide) {
+        const d2 t = *reinterpret_cast<const d2*>(p.W + (int64_t)ic * p.ldw + j0 + 2 * cp);
+        wraw[it][0] = t.x;
+        wraw[it][1] = t.y;
+      } else {
+        wraw[it][0] = p.W[(int64_t)ic * p.ldw + jc0];
+        wraw[it][1] = p.W[(int64_t)ic * p.ldw + jc1];
+      }
+      urow[it] = p.u ? p.u[ic] : 0.0;
+    }
+    if (p.u) {
+      vcol[0] = p.v[jc0];
+      vcol[1] = p.v[jc1];
+    }
+  }
 
   // pass 1: r2
   double r2[8][2];
@@ -150,15 +190,10 @@ __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int j = j0 + 2 * cp + c;
-      double w = 0.0;
-      if (i < p.n1 && j < p.n2) {
-        w = p.w_scale * p.W[(int64_t)i * p.ldw + j];
-        if (p.u) w = __builtin_fma(p.uv_scale * p.u[i], p.v[j], w);
-        if (p.sym) {
-          if (j > i) w = 0.0;
-          else if (j < i) w *= 2.0;
-        }
-      }
+      double w = p.w_scale * wraw[it][c];
+      if (p.u) w = __builtin_fma(p.uv_scale * urow[it], vcol[c], w);
+      if (p.sym) w = (j > i) ? 0.0 : ((j < i) ? w * 2.0 : w);
+      w = (i < p.n1 && j < p.n2) ? w : 0.0;
       double g, h;
       corr_gh<KID>(r2[it][c], g, h);
       sg = __builtin_fma(w, g, sg);
@@ -185,10 +220,12 @@ __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_
   if (tid < 2) out[tid] = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
   __syncthreads();
 
-  // pass 2: per-dimension sums  -sum wh ds_k^2 / l_k
+  // pass 2: per-dimension sums  -sum wh ds_k^2 / l_k   (d <= 8: the staged coordinates of pass 1 are still in LDS)
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
-    stage(k0);
-    __syncthreads();
+    if (p.d > KM_DC) {
+      stage(k0);
+      __syncthreads();
+    }
     double sk[KM_DC];
 #pragma unroll
     for (int kk = 0; kk < KM_DC; ++kk) {
@@ -213,7 +250,7 @@ __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_
 }
 
 template <int KID, int FORM = 0>
-__global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {
+__global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {  // (216 VGPRs, two workgroups per CU; capped at 168 it spills: 8.9 -> 9.3 ms)
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
   __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
   __shared__ double sRed[4][KM_DC + 2];

@@ -136,27 +136,36 @@ __device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC
 
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
     // 64 points x 8 coords for each side = 512 + 512 values, 256 threads -> 2 + 2 each
+    {
+      // unconditional loads from clamped indices, selected afterwards (predicated loads each cost a full memory round trip)
+      double ra[2], rb[2];
+      const int kc = min(k0 + (tid & 7), p.d - 1);
+      const double s = p.ls[kc];
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      const int q = tid + 256 * rep;
-      const int pt = q >> 3, kk = q & 7;
-      const int k = k0 + kk;
-      double va = 0.0, vb = 0.0;
-      if (k < p.d) {
-        const double s = p.ls[k];
+      for (int rep = 0; rep < 2; ++rep) {
+        const int pt = (tid + 256 * rep) >> 3;
+        ra[rep] = p.a[(int64_t)min(i0 + pt, p.n1 - 1) * p.d + kc];
+        rb[rep] = p.b[(int64_t)min(j0 + pt, p.n2 - 1) * p.d + kc];
+      }
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int q = tid + 256 * rep;
+        const int pt = q >> 3, kk = q & 7;
+        const bool live = k0 + kk < p.d;
+        double va, vb;
         if constexpr (FORM == 0) {
           // one division per thread and pass (its two points share the coordinate k) instead of four: the staging divisions were
           // ~9 of the ~61 fp64 instructions per output element.  (FORM 1 keeps x / l: it restates gpflow's arithmetic to the bit.)
           const double inv = 1.0 / s;
-          if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] * inv;
-          if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] * inv;
+          va = ra[rep] * inv;
+          vb = rb[rep] * inv;
         } else {
-          if (i0 + pt < p.n1) va = p.a[(int64_t)(i0 + pt) * p.d + k] / s;
-          if (j0 + pt < p.n2) vb = p.b[(int64_t)(j0 + pt) * p.d + k] / s;
+          va = ra[rep] / s;
+          vb = rb[rep] / s;
         }
+        sA[pt][kk] = (live && i0 + pt < p.n1) ? va : 0.0;
+        sBt[kk][pt] = (live && j0 + pt < p.n2) ? vb : 0.0;
       }
-      sA[pt][kk] = va;
-      sBt[kk][pt] = vb;
     }
     __syncthreads();
     double b0[KM_DC], b1[KM_DC];
