@@ -163,7 +163,7 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
     by = (L & 7) + 8 * cq;
     bx = slot - cq * p.nwg;
   }
-  static_assert(!DMA || (TA == 0 && TB == 1 && AXF == 0), "the LDS-DMA staging exists for the NT form only");
+  static_assert(!DMA || (TA == 0 && AXF == 0 && (TB == 1 || BN == 64)), "the LDS-DMA staging exists for the NT form and for NN with 64-wide tiles");
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = GemmSmem<TA, TB, BM, BN>::A_ELEMS;
   constexpr int B_ELEMS = GemmSmem<TA, TB, BM, BN>::B_ELEMS;
@@ -402,11 +402,24 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
         const int row = rbase + (lane >> 3);
         glds16(p.A + (int64_t)(m0 + row) * p.lda + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sa + rbase * GEMM_LDK);
       }
+      if constexpr (TB == 1) {
 #pragma unroll
-      for (int i = 0; i < BN / 32; ++i) {
-        const int rbase = (i * 4 + wave_u) * 8;
-        const int row = rbase + (lane >> 3);
-        glds16(p.B + (int64_t)(n0 + row) * p.ldb + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sb + rbase * GEMM_LDK);
+        for (int i = 0; i < BN / 32; ++i) {
+          const int rbase = (i * 4 + wave_u) * 8;
+          const int row = rbase + (lane >> 3);
+          glds16(p.B + (int64_t)(n0 + row) * p.ldb + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sb + rbase * GEMM_LDK);
+        }
+      } else {
+        // NN: B is stored K x N, so a stage is 16 k-rows of 64 contiguous columns = 512 B each: one instruction lands two rows.
+        // The image is [16][64] UNPADDED (the DMA writes lane-linear); conflict-free fragment reads come from the SOURCE side:
+        // row k keeps its 16-byte chunks at position chunk ^ 8 ((k >> 2) & 1), so the lane groups g and g + 1 of a ds_read_b64
+        // half-wave (k = 4 g + j: rows 4 apart) use complementary halves of the 64 banks.
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int rbase = (i * 4 + wave_u) * 2;
+          const int row = rbase + (lane >> 5);
+          glds16(p.B + (int64_t)(k0 + row) * p.ldb + n0 + 2 * ((lane & 31) ^ (8 * ((row >> 2) & 1))), sb + rbase * BN);
+        }
       }
     };
     const int swz_d = kc_swz(r);
@@ -425,9 +438,15 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int col = wn * (BN / 2) + b * 16 + r;
-        const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 2 * ((2 * g) ^ swz_d));
-        const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 2 * ((2 * g + 1) ^ swz_d));
-        fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
+        if constexpr (TB == 1) {
+          const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 2 * ((2 * g) ^ swz_d));
+          const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_LDK + 2 * ((2 * g + 1) ^ swz_d));
+          fb[b][0] = lo.x; fb[b][1] = lo.y; fb[b][2] = hi.x; fb[b][3] = hi.y;
+        } else {
+          const int pos = 2 * ((col >> 1) ^ (8 * (g & 1))) + (col & 1);  // (row 4 g + j: (row >> 2) & 1 == g & 1)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[b][j] = sb[(4 * g + j) * BN + pos];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -590,6 +609,16 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
         hipLaunchKernelGGL((gemm_f64_kernel<0, 1, (BM > 64 ? 64 : BM), (BN > 64 ? 64 : BN), 1, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), pad, st, p);
       else
         hipLaunchKernelGGL((gemm_f64_kernel<0, 1, BM, BN, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), pad, st, p);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (TA == 0 && TB == 0 && BM == 64 && BN == 64) {
+    // NN on full 64 x 64 tiles (the L^-1 build, triangular solves with matrix right-hand sides): both operands by LDS-DMA as well
+    static const int dma_nn = getenv("GPRX_GEMM_DMA_NN") ? atoi(getenv("GPRX_GEMM_DMA_NN")) : 1;
+    if (dma_nn && p.M % BM == 0 && p.N % BN == 0 && p.K % GEMM_BK == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0 && nsplit == 1 &&
+        (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 && p.strideA % 2 == 0 && p.strideB % 2 == 0 &&
+        p.cellA % 2 == 0 && p.cellB % 2 == 0) {
+      hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 64, 64, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
       return hipGetLastError();
     }
   }
