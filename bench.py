@@ -40,7 +40,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 N_TRAIN, DIM, N_TEST = 4096, 8, 100_000
-CELLS_PER_STEP = 128  # cells per batched launch sequence per GPU per step (measured on one box: 16 -> 1600, 64 -> 1840, 96 -> 1880, 128 -> 1896 fits/s)
+CELLS_PER_STEP = 256  # cells per batched launch sequence per GPU per step (round 3, one box: 128 -> 2138, 192 -> 2157, 256 -> 2168, 384 -> 2173 fits/s;
+                      # round 1: 16 -> 1600, 64 -> 1840, 96 -> 1880, 128 -> 1896); 256 cells = 35 GB of the 288 GB
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz: half the f32 matrix rate of MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
