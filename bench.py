@@ -130,6 +130,29 @@ def main():
     distributed = world > 1 or "RANK" in os.environ
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    # Ranks are launched by `python -m torch.distributed.run` (the driver) or by spawn_ranks above; either way THIS process does not
+    # import torch: RANK / LOCAL_RANK / WORLD_SIZE come from the environment, the 128-byte RCCL id travels through files
+    # (gpras_amd.comm.file_rendezvous: every rank first reports that it can load RCCL, so nobody blocks in ncclCommInitRank
+    # behind a rank that cannot), timing barriers and the maximum over ranks go through gprx_comm_* -- ONE HIP runtime and ONE
+    # RCCL per rank (VERDICT r2: torch's own HIP / HSA / RCCL tree beside ROCm's was the source of the round-2 failures).
+    # GPRX_BENCH_TORCH=1 selects the round-2 path instead: torch is imported FIRST (so that libgprx.so binds to the HIP runtime torch
+    # loaded) and torch.distributed launches the collective's bootstrap.  There is no automatic fall-back from one to the other:
+    # once libgprx has initialised ROCm's HIP runtime, torch finds no GPU in the same process (measured: "No HIP GPUs are
+    # available") -- a failed torch-free rendezvous ends every rank with a message instead.
+    torch = dist = comm = None
+    comm_error = ""
+    launcher = "single process"
+    use_torch = distributed and os.environ.get("GPRX_BENCH_TORCH") == "1"
+    if use_torch:
+        import torch  # noqa: PLC0415
+        import torch.distributed as dist  # noqa: PLC0415
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        launcher = "torch.distributed (GPRX_BENCH_TORCH=1)"
+
     import fcntl
 
     from gpras_amd import _build, _lib
@@ -141,38 +164,31 @@ def main():
         _build.build()
     lib = _lib.load()
     device = local_rank if distributed else 0
-    # Ranks are launched by `python -m torch.distributed.run` (the driver) or by spawn_ranks above; either way THIS process never
-    # imports torch: RANK / LOCAL_RANK / WORLD_SIZE come from the environment, the 128-byte RCCL id travels through files
-    # (gpras_amd.comm.file_rendezvous: every rank first reports that it can load RCCL, so nobody blocks in ncclCommInitRank
-    # behind a rank that cannot), timing barriers and the maximum over ranks go through gprx_comm_* -- ONE HIP runtime and ONE
-    # RCCL per rank (VERDICT r2: torch's own HIP / HSA / RCCL tree beside ROCm's was the source of the round-2 failures).
-    # GPRX_BENCH_TORCH=1 (or a failed rendezvous, agreed by all ranks) selects the older path through torch.distributed.
-    torch = dist = comm = None
-    comm_error = ""
-    launcher = "single process"
-    if distributed and os.environ.get("GPRX_BENCH_TORCH") != "1":
+    if distributed:
         from gpras_amd.comm import Communicator, agree, default_id_prefix
 
         prefix = default_id_prefix()
         try:
-            comm = Communicator.bootstrap(device, rank, world, id_file=prefix)
-            launcher = "torch-free ranks: environment + file rendezvous, gprx_comm_* (RCCL behind the C ABI) for barriers, max and the gather"
+            # (with a process group the id travels through it; without, through files)
+            comm = Communicator.bootstrap(device, rank, world, id_file=None if use_torch else prefix)
+            if not use_torch:
+                launcher = "torch-free ranks: environment + file rendezvous, gprx_comm_* (RCCL behind the C ABI) for barriers, max and the gather"
         except Exception as exc:  # noqa: BLE001
             comm, comm_error = None, f"{type(exc).__name__}: {exc}"
-        if world > 1 and not agree(prefix, "comm", rank, world, comm is not None):
-            # (every rank takes the same branch: one rank without a communicator sends all of them to the torch.distributed path)
+        if use_torch:
+            ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm, comm_error = None, comm_error or "another rank could not create its communicator"
+        elif world > 1 and not agree(prefix, "comm", rank, world, comm is not None):
             if comm is not None:
                 comm.close()
             comm, comm_error = None, comm_error or "another rank could not create its communicator"
-    if distributed and comm is None:
-        import torch  # noqa: PLC0415
-        import torch.distributed as dist  # noqa: PLC0415
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        launcher = f"torch.distributed fallback ({comm_error or 'GPRX_BENCH_TORCH=1'})"
+        if comm is None and not use_torch:
+            sys.stderr.write(f"bench.py rank {rank}: the communicator could not be created on every rank ({comm_error}); "
+                             "GPRX_BENCH_TORCH=1 selects the torch.distributed launch path\n")
+            sys.exit(3)
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
     # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
@@ -266,7 +282,7 @@ def main():
             "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end",
             "collective": ("none (one process)" if not distributed else "gprx_comm_all_gather (RCCL behind the C ABI, device-resident buffers)" if comm is not None
                            else f"torch.distributed all_gather (fallback: {comm_error})"),
-            "launcher": launcher,
+            "launcher": launcher if (comm is not None or not distributed) else f"{launcher}; gather through torch.distributed ({comm_error})",
             "hip_and_rccl_libraries_mapped": mapped_runtimes(),
         },
     }
@@ -711,7 +727,7 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
-    elif distributed:
+    if use_torch:
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
