@@ -460,7 +460,12 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__
 
 // A21: first row below the diagonal block (rows_below rows, lda); stage: this panel's staged L11 (64 x 64) followed by
 // the 64 reciprocal pivots.  grid = (ceil(rows_below / (64 RT)), cells).
-template <int RT, int OCC, bool SCALAR_L = false, bool NO_LDS_L = false, bool WAVE_LOCAL = false>
+// FUSE_K64: as in potrf_panel_kernel -- the K = 64 update of these 64 columns by the 64 columns left of them (which the schedule
+// would launch between the previous panel and this one) is applied to this workgroup's rows on their way in: with many cells per
+// launch that update is HBM-bound (16 bytes of C traffic per 128 flops), and this kernel reads and writes the very same columns
+// anyway.  Operation for operation the general NT kernel's arithmetic (accumulators from zero, stages of 16 along k, instruction j
+// takes k = k0 + 4 g + j, C + (-1) * sum with one rounding): bit-identical to the separate launch.
+template <int RT, int OCC, bool SCALAR_L = false, bool NO_LDS_L = false, bool WAVE_LOCAL = false, bool FUSE_K64 = false>
 __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
                                                               const double* __restrict__ stage, int64_t cs) {
   constexpr int WG_ROWS = 64 * RT, WROWS = 16 * RT;
@@ -486,12 +491,58 @@ __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict
         valid[rt][q] = idx < rows_below;
         rowp[rt][q] = A21 + (int64_t)(valid[rt][q] ? idx : 0) * lda + r;
       }
+    d4 upd[FUSE_K64 ? RT : 1][4];
+    if constexpr (FUSE_K64) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) upd[rt][kt] = d4{0.0, 0.0, 0.0, 0.0};
+      const double* arow[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int idx = row0 + WROWS * wave + 16 * rt + r;  // A operand: lane (g, r) supplies row r of the tile, k = 4 g + j
+        arow[rt] = A21 + (int64_t)(idx < rows_below ? idx : 0) * lda - NB + 4 * g;
+      }
+      const double* brow = A21 - (int64_t)NB * lda + (int64_t)r * lda - NB + 4 * g;  // B operand: the diagonal block's rows, previous 64 columns
+#pragma unroll
+      for (int k0 = 0; k0 < NB; k0 += 16) {
+        double fa[RT][4], fb[4][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const d2 lo = *reinterpret_cast<const d2*>(arow[rt] + k0), hi = *reinterpret_cast<const d2*>(arow[rt] + k0 + 2);
+          fa[rt][0] = lo.x; fa[rt][1] = lo.y; fa[rt][2] = hi.x; fa[rt][3] = hi.y;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const double* bp = brow + (int64_t)(16 * kt) * lda + k0;
+          const d2 lo = *reinterpret_cast<const d2*>(bp), hi = *reinterpret_cast<const d2*>(bp + 2);
+          fb[kt][0] = lo.x; fb[kt][1] = lo.y; fb[kt][2] = hi.x; fb[kt][3] = hi.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) upd[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][j], fb[kt][j], upd[rt][kt], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) acc[rt][kt][q] = rowp[rt][q][kt * 16];
+    if constexpr (FUSE_K64) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double v = -1.0 * upd[rt][kt][q];
+            acc[rt][kt][q] = __builtin_fma(1.0, acc[rt][kt][q], v);
+          }
+    }
     // L11 image and the reciprocal pivots (staged by the diagonal workgroup of this panel)
     if constexpr (!NO_LDS_L) {
       for (int e = tid; e < NB * NB / 2; e += 256) {
@@ -1144,8 +1195,12 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
                          stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
     } else if (split_panel) {
       // diagonal block: one workgroup per cell (the `last` role of the panel kernel: L11 staged, L11^-1, pivots) ...
-      hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out, prev_stage,
-                         prev_dst, prev_pw, cs, info_stride);
+      if (fuse)
+        hipLaunchKernelGGL((potrf_panel_kernel<2, 2, true>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out,
+                           prev_stage, prev_dst, prev_pw, cs, info_stride);
+      else
+        hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out, prev_stage,
+                           prev_dst, prev_pw, cs, info_stride);
       // ... then the rows below it, 128 per workgroup
       if (rows_below > 0) {
         // default: no L11 image in LDS (the 8 x 8 diagonal sub-blocks and pivots through scalar loads, the MFMA operands straight
@@ -1156,7 +1211,10 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
         // workgroup barriers become wave-scope fences (another -0.3 ms).  GPRX_ROWS_LDS=1 restores the LDS image and the barriers
         // (same values either way).
         static const bool rows_lds = getenv("GPRX_ROWS_LDS") != nullptr;
-        if (rows_lds)
+        if (fuse)
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 2, true, true, true, true>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
+                             Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs);
+        else if (rows_lds)
           hipLaunchKernelGGL((potrf_rows_kernel<2, 3, false, false>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
                              Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs);
         else
@@ -1231,7 +1289,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
     }
     const int h = ((w / NB + 1) / 2) * NB;
     self(self, c0, h);
-    if (h == NB && w - h == NB && pwidth != PW && !split_panel && fuse_ok && tune.panel_rows != 256 && tune.panel_occ != 3) {
+    // (split panels fuse too since round 3, GPRX_FUSE_K64_SPLIT=0 restores the separate launch: the update is HBM-bound there)
+    static const bool fuse_split = !(getenv("GPRX_FUSE_K64_SPLIT") && atoi(getenv("GPRX_FUSE_K64_SPLIT")) == 0);
+    if (h == NB && w - h == NB && pwidth != PW && (!split_panel || fuse_split) && fuse_ok && tune.panel_rows != 256 && tune.panel_occ != 3) {
       panel(c0 + h, NB, true);  // the K = 64 update of the right panel rides in its own kernel
       return;
     }
