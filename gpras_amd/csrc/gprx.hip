@@ -2792,6 +2792,16 @@ extern "C" int gprx_chain_stamps(unsigned long long* out16) {
 }
 #endif
 
+#ifdef GPRX_PANEL_ACC
+int gprx_panel_acc(unsigned long long* out8, int reset) {
+  if (reset) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(gprx::g_panel_acc), z, sizeof(z));
+  }
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(gprx::g_panel_acc), sizeof(unsigned long long) * 8);
+  return 0;
+}
+#endif
 #ifdef GPRX_PANEL_STAMPS
 int gprx_panel_stamps(unsigned long long* out64) {
   hipMemcpyFromSymbol(out64, HIP_SYMBOL(gprx::g_panel_stamps), sizeof(unsigned long long) * 64);

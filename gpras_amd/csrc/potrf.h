@@ -23,6 +23,26 @@
 
 namespace gprx {
 
+// GPRX_PANEL_ACC (development builds, tools/panel_acc.sh): phase durations of panel workgroup 0 (a rows workgroup) summed over
+// every panel launch of a factorisation -- [0] launches, [1] loads, [2] sub-panel 0, [3] sub-panels 1-3, [4] sub-panels 4-7,
+// [5] stores (shader clocks)
+#ifdef GPRX_PANEL_ACC
+__device__ unsigned long long g_panel_acc[8];
+#define PACC_DECL unsigned long long pacc_prev_ = 0;
+#define PACC(i)                                                                                                       \
+  {                                                                                                                   \
+    if ((i) == 5) __builtin_amdgcn_s_waitcnt(0);                                                                      \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && gridDim.x > 2) {                                    \
+      if ((i) > 0) atomicAdd(&g_panel_acc[i], t_ - pacc_prev_);                                                       \
+      else atomicAdd(&g_panel_acc[0], 1ull);                                                                          \
+    }                                                                                                                 \
+    pacc_prev_ = t_;                                                                                                  \
+  }
+#else
+#define PACC_DECL
+#define PACC(i)
+#endif
 #ifdef GPRX_PANEL_STAMPS
 __device__ unsigned long long g_panel_stamps[64];
 #define PSTAMP(i)                                                                                                     \
@@ -245,6 +265,8 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
     if (last && c.tid < 2 * NB) c.ident = c.tid - NB;  // (rows of A21 leave through the final store pass)
   }
   PSTAMP(0)
+  PACC_DECL
+  PACC(0)
 
   // ---- load straight into the accumulator layout: 16 RT loads per lane, all in flight ----
   // Every load is unconditional (rows outside the matrix read row 0 of the diagonal block instead) and the
@@ -345,18 +367,22 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
       }
   }
   PSTAMP(1)
+  PACC(1)
 
   panel_step<0, RT>(acc, c);
   PSTAMP(2)
+  PACC(2)
   panel_step<1, RT>(acc, c);
   panel_step<2, RT>(acc, c);
   panel_step<3, RT>(acc, c);
   PSTAMP(3)
+  PACC(3)
   panel_step<4, RT>(acc, c);
   panel_step<5, RT>(acc, c);
   panel_step<6, RT>(acc, c);
   panel_step<7, RT>(acc, c);
   PSTAMP(4)
+  PACC(4)
   if (!last) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -373,6 +399,7 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
   }
   if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
   PSTAMP(5)
+  PACC(5)
 }
 
 // ---- split panel (many cells per launch): rows only ---------------------------------------------------
