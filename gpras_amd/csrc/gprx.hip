@@ -698,7 +698,12 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   double* X0 = h->garena.p;
   double* T0 = h->garena.p + (int64_t)np * ld;
   double* K0 = h->arena.p;
-  for (int c = 0; c < count; ++c) HIPCHK(h, hipMemsetAsync(X0 + (int64_t)c * gs, 0, sizeof(double) * h->np * ld, st));
+  // (X needs no zeroing: scatter_inv_diag writes the diagonal blocks whole -- zeros above the diagonal included --, every tile
+  // below them is written with beta = 0 before it is read, and the triangular K ranges of the products never reach a tile above
+  // the diagonal; the 128 memsets of 134 MB were 1.5 % of a batched evaluation.  "poison_workspace" = 1 fills X with NaN patterns
+  // instead, for the test that proves it.)
+  if (h->tune.poison_workspace)
+    for (int c = 0; c < count; ++c) HIPCHK(h, hipMemsetAsync(X0 + (int64_t)c * gs, 0xff, sizeof(double) * h->np * ld, st));
   // 64 x 64 tiles throughout: with many cells per launch they beat the 128 x 128 tiles on these triangular products
   // (measured at 32 cells of N = 4096: 52.8 ms against 60.7 ms per batched objective + gradient)
   const int tile = h->tune.update_tile ? h->tune.update_tile : 64;
@@ -745,7 +750,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   if ((rc = ensure(h, h->Xinv, sizeof(double) * h->np * ld))) return rc;
   if ((rc = ensure(h, h->Tmp, sizeof(double) * h->np * ld))) return rc;
   hipStream_t st = h->stream;
-  HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0, sizeof(double) * h->np * ld, st));
+  if (h->tune.poison_workspace) HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0xff, sizeof(double) * h->np * ld, st));  // (see exact_gradient_batch)
   HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
   // K^-1 = X^T X on the lower tiles, into Tmp: NT product of Xt = L^-T (X transposed in place) with itself
   HIPCHK(h, transpose_inplace(st, h->Xinv.p, ld, np));
@@ -2822,6 +2827,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "dag" && value >= -1 && value <= 1) t.dag = value;
   else if (k == "cell_kernel" && value >= -1 && value <= 1) t.cell_kernel = value;
   else if (k == "split_updates" && value >= 0 && value <= 1) t.split_updates = value;
+  else if (k == "poison_workspace" && value >= 0 && value <= 1) t.poison_workspace = value;
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
   else return false;
   return true;

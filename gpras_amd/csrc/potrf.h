@@ -1040,6 +1040,7 @@ struct PotrfTuning {
   int panel_occ = 0;     // 3: panel kernel compiled for 3 workgroups per CU (168 registers, small spills) instead of 2
   int inblock = 0;       // 1: right-looking K = 64 strips inside an outer block instead of the recursive halving
   int split_panel = 0;   // 1: always the split panel (diagonal workgroup + rows kernel), -1: never, 0: from 24 cells per launch on
+  int poison_workspace = 0;  // testing: the gradient's L^-1 workspace starts as NaN patterns (nothing may depend on its old contents)
   int split_updates = 0; // lone matrix: 1 = look-ahead split of the K >= 256 updates over a side stream (see potrf_lower; measured
                          // slower: 2.17 -> 2.66 ms at N = 4096), 0 = every update whole on the main stream (default)
   int cell_kernel = 0;   // batched cells: 1 = always one workgroup per cell (potrf_cell.h), -1 never, 0 = for np <= 1024 and >= 256 cells

@@ -346,6 +346,8 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * blocks in one workgroup, every other tile task claimed from a queue and ordered by per-tile version counters in device memory;
  * deterministic, within rounding of the default; default 0 = the launch-per-panel schedule, which measured faster on MI355X:
  * DESIGN.md section 7.2).
+ * "poison_workspace" (testing, 1: the L^-1 workspace of the gradient starts as NaN patterns instead of whatever it held -- the
+ * gradient never depends on its old contents, and no longer zeroes it).
  * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical.
  * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution. */
 int gprx_set_tuning(const char* key, int value);

@@ -252,3 +252,30 @@ def test_predict_batch_matches_oracle(lib):
             assert np.max(np.abs(means[c] - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(vars_[c] - rv) / rv) <= 1e-8
     finally:
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("n", [320, 1000])
+def test_gradient_does_not_depend_on_old_workspace_contents(lib, n):
+    """The L^-1 workspace of the gradient is no longer zeroed (every tile that is read was written first, the triangular K ranges
+    never reach a tile above the diagonal): with the workspace poisoned by NaN patterns ("poison_workspace") the single and the
+    batched gradient are the same numbers, bit for bit."""
+    d = 4
+    x, y, _ = make_regression(n, d, n_outputs=3, n_test=8, config=1, unit=n)
+    theta = pack_theta(1.1, 0.8, 0.05)
+    out = {}
+    for poison in (0, 1):
+        h = make_handle(lib, n, d, "RBF", False, x, y)
+        try:
+            check(lib.gprx_set_handle_tuning(h, b"poison_workspace", poison), h)
+            loss, grad = C.c_double(), np.zeros(theta.size)
+            check(lib.gprx_objective(h, 1, ptr(theta), None, ALL, C.byref(loss), ptr(grad)), h)
+            units = np.array([0, 1, 2, 1], dtype=np.int32)
+            thetas = np.ascontiguousarray(np.tile(theta, (4, 1)) + 0.01 * np.arange(4)[:, None])
+            losses, grads = np.zeros(4), np.zeros((4, theta.size))
+            check(lib.gprx_objective_batch(h, 4, ptr(units), ptr(thetas), None, ALL, ptr(losses), ptr(grads)), h)
+            out[poison] = (loss.value, grad, losses, grads)
+        finally:
+            lib.gprx_destroy(h)
+    assert np.all(np.isfinite(out[1][1])) and np.all(np.isfinite(out[1][3]))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
