@@ -716,6 +716,7 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   TraceArgs ta{h->X.p, h->X.p, nullptr, T0, ld, K0 + h->off_alpha, K0 + h->off_alpha, -1.0, 1.0, (int)h->n, (int)h->n, h->d, 0.0, 1, h->gpartial.p,
                nullptr, 0, tiles};
   ta.cell_par = h->cellpar.p;
+  ta.iso = h->ard ? 0 : 1;
   ta.w_stride = gs;
   ta.uv_stride = cs;
   ta.partial_stride = ps;
@@ -761,6 +762,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   const int width = 2 + h->d;
   if ((rc = ensure(h, h->partial, sizeof(double) * ((size_t)tiles * tiles * width + width)))) return rc;
   TraceArgs ta{h->X.p, h->X.p, h->invls.p, h->Tmp.p, ld, h->alpha.p, h->alpha.p, -1.0, 1.0, (int)h->n, (int)h->n, h->d, t.variance, 1, h->partial.p, nullptr, 0, tiles};
+  ta.iso = h->ard ? 0 : 1;
   HIPCHK(h, launch_trace(st, h->kid, with_form(ta, h), tiles * tiles));
   double* sums = h->partial.p + (size_t)tiles * tiles * width;
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, h->partial.p, tiles * tiles, width, sums);

@@ -37,12 +37,16 @@ struct TraceArgs {
   int64_t a_stride = 0, b_stride = 0, v_stride = -1, wh_stride = 0;  // v_stride < 0: v advances like u
   int scale_inv_noise = 0;  // 1: w_scale = uv_scale = 1 / table[1] (the sparse model's 1 / s)
   int form = 0;             // distance form of r2 inside g and h (kmat.h); the factors ds_k of the derivatives stay differences
+  int iso = 0;              // 1: ONE lengthscale for every dimension (the reference's default kernels): only the sum over k of the
+                            // lengthscale traces is wanted -- partial[wg][2] = -sum w v h r2 / l, partial[wg][3 ..] = 0
 };
 
 // One workgroup per 64 x 64 tile.  Thread mapping as kmat_kernel: 8 rows x 2 columns per thread.
 // Output per workgroup (deterministic two-stage reduction, no atomics):
 //   partial[wg][0] = sum w g          partial[wg][1] = sum_{i == j} w      partial[wg][2 + k] = -sum w v h ds_k^2 / l_k
-template <int KID, int FORM = 0>
+// ISO (difference form only): sum_k ds_k^2 IS the r2 of pass 1, so the per-dimension pass 2 (a third of the kernel's fp64
+// instructions) reduces to one FMA per element.
+template <int KID, int FORM = 0, int ISO = 0>
 __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_DC], double (*sBt)[KM_T], double (*sRed)[KM_DC + 2]) {
   if (p.cell_par) {
     const double* par = p.cell_par + (int64_t)blockIdx.y * CELL_PAR;
@@ -220,6 +224,20 @@ __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_
   if (tid < 2) out[tid] = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
   __syncthreads();
 
+  if constexpr (ISO != 0) {
+    static_assert(FORM == 0, "the isotropic shortcut needs r2 as the plain sum of squared differences");
+    double acc = 0.0;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      acc = __builtin_fma(wh[it][0], r2[it][0], acc);
+      acc = __builtin_fma(wh[it][1], r2[it][1], acc);
+    }
+    block_sum_store(acc, 2);
+    __syncthreads();
+    if (tid == 0) out[2] = -(sRed[0][2] + sRed[1][2] + sRed[2][2] + sRed[3][2]) / p.ls[0];
+    if (tid >= 1 && tid < p.d) out[2 + tid] = 0.0;
+    return;
+  }
   // pass 2: per-dimension sums  -sum wh ds_k^2 / l_k   (d <= 8: the staged coordinates of pass 1 are still in LDS)
   for (int k0 = 0; k0 < p.d; k0 += KM_DC) {
     if (p.d > KM_DC) {
@@ -249,12 +267,12 @@ __device__ __forceinline__ void trace_body(TraceArgs p, int bx, double (*sA)[KM_
   }
 }
 
-template <int KID, int FORM = 0>
+template <int KID, int FORM = 0, int ISO = 0>
 __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {  // (216 VGPRs, two workgroups per CU; capped at 168 it spills: 8.9 -> 9.3 ms)
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
   __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
   __shared__ double sRed[4][KM_DC + 2];
-  trace_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt, sRed);
+  trace_body<KID, FORM, ISO>(p, (int)blockIdx.x, sA, sBt, sRed);
 }
 // Two contractions in one launch (the sparse model's Kuf and Kuu terms): workgroups [0, first) take p, the rest q.
 template <int KID, int FORM = 0>
@@ -378,6 +396,8 @@ inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid, i
   case K_:                                                                    \
     if (p.form)                                                               \
       hipLaunchKernelGGL((trace_kernel<K_, 1>), g, b, 0, st, p);              \
+    else if (p.iso && !p.wh_out && p.d <= KM_DC)                              \
+      hipLaunchKernelGGL((trace_kernel<K_, 0, 1>), g, b, 0, st, p);           \
     else                                                                      \
       hipLaunchKernelGGL((trace_kernel<K_, 0>), g, b, 0, st, p);              \
     break;
