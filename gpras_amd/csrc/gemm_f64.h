@@ -163,7 +163,8 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
     by = (L & 7) + 8 * cq;
     bx = slot - cq * p.nwg;
   }
-  static_assert(!DMA || (TA == 0 && AXF == 0 && (TB == 1 || BN == 64)), "the LDS-DMA staging exists for the NT form and for NN with 64-wide tiles");
+  static_assert(!DMA || (AXF == 0 && (TA == 0 || BM == 64) && (TB == 1 || BN == 64)),
+                "the LDS-DMA staging exists for k-contiguous operands and for m/n-contiguous operands of 64-wide tiles");
   constexpr int TM = BM / 32, TN = BN / 32;
   constexpr int A_ELEMS = GemmSmem<TA, TB, BM, BN>::A_ELEMS;
   constexpr int B_ELEMS = GemmSmem<TA, TB, BM, BN>::B_ELEMS;
@@ -396,11 +397,21 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
     auto dma_fill = [&](int k0, int buf) {
       double* sa = smem + buf * (A_ELEMS + B_ELEMS);
       double* sb = sa + A_ELEMS;
+      if constexpr (TA == 0) {
 #pragma unroll
-      for (int i = 0; i < BM / 32; ++i) {
-        const int rbase = (i * 4 + wave_u) * 8;
-        const int row = rbase + (lane >> 3);
-        glds16(p.A + (int64_t)(m0 + row) * p.lda + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sa + rbase * GEMM_LDK);
+        for (int i = 0; i < BM / 32; ++i) {
+          const int rbase = (i * 4 + wave_u) * 8;
+          const int row = rbase + (lane >> 3);
+          glds16(p.A + (int64_t)(m0 + row) * p.lda + k0 + 2 * ((lane & 7) ^ kc_swz(row)), sa + rbase * GEMM_LDK);
+        }
+      } else {
+        // TN: A is stored K x M -- the image and its source-side swizzle are those of the NN form's B operand (below)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int rbase = (i * 4 + wave_u) * 2;
+          const int row = rbase + (lane >> 5);
+          glds16(p.A + (int64_t)(k0 + row) * p.lda + m0 + 2 * ((lane & 31) ^ (8 * ((row >> 2) & 1))), sa + rbase * BM);
+        }
       }
       if constexpr (TB == 1) {
 #pragma unroll
@@ -431,9 +442,15 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
         const int row = wm * (BM / 2) + a * 16 + r;
-        const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 2 * ((2 * g) ^ swz_d));
-        const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 2 * ((2 * g + 1) ^ swz_d));
-        fa[a][0] = lo.x; fa[a][1] = lo.y; fa[a][2] = hi.x; fa[a][3] = hi.y;
+        if constexpr (TA == 0) {
+          const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 2 * ((2 * g) ^ swz_d));
+          const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_LDK + 2 * ((2 * g + 1) ^ swz_d));
+          fa[a][0] = lo.x; fa[a][1] = lo.y; fa[a][2] = hi.x; fa[a][3] = hi.y;
+        } else {
+          const int pos = 2 * ((row >> 1) ^ (8 * (g & 1))) + (row & 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[a][j] = sa[(4 * g + j) * BM + pos];
+        }
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
@@ -619,6 +636,16 @@ inline hipError_t launch_gemm_t(hipStream_t st, GemmArgs p, int batch, int nspli
         (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 && p.strideA % 2 == 0 && p.strideB % 2 == 0 &&
         p.cellA % 2 == 0 && p.cellB % 2 == 0) {
       hipLaunchKernelGGL((gemm_f64_kernel<0, 0, 64, 64, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (TA == 1 && TB == 0 && BM == 64 && BN == 64) {
+    // TN on full 64 x 64 tiles (K^-1 = X^T X of the gradient, X = L^-1): both operands are m / n-contiguous, both by LDS-DMA
+    static const int dma_tn = getenv("GPRX_GEMM_DMA_TN") ? atoi(getenv("GPRX_GEMM_DMA_TN")) : 1;
+    if (dma_tn && p.M % BM == 0 && p.N % BN == 0 && p.K % GEMM_BK == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0 && nsplit == 1 &&
+        (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 && p.strideA % 2 == 0 && p.strideB % 2 == 0 &&
+        p.cellA % 2 == 0 && p.cellB % 2 == 0) {
+      hipLaunchKernelGGL((gemm_f64_kernel<1, 0, 64, 64, 0, 0, 1>), dim3(p.nwg, batch, nsplit), dim3(256), 0, st, p);
       return hipGetLastError();
     }
   }

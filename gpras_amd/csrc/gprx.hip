@@ -681,6 +681,13 @@ int select_slot(gprx_handle h, int slot) {
   return GPRX_OK;
 }
 
+// K^-1 = X^T X (X = L^-1) as the TN product on the LDS-DMA kernel (default), or GPRX_KINV_TN=0: X transposed in place and the NT
+// product of L^-T with itself (one more pass over X: 5.9 ms per 128 cells of N = 4096); the same sums in the same k order.
+bool kinv_tn() {
+  static const bool v = !(getenv("GPRX_KINV_TN") && atoi(getenv("GPRX_KINV_TN")) == 0);
+  return v;
+}
+
 // Gradients of the LML for every cell of the batch just factorised (slots 0 .. count-1): the single-cell stages
 // (L^-1 by bottom-up doubling, K^-1 = L^-T L^-1 on the lower tiles, one trace pass for all 2 + d derivatives) with
 // the cell index in the grid.  g: count x ntheta, constrained parameters (variance, lengthscales, noise); rows of
@@ -710,9 +717,13 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   HIPCHK(h, trtri_lower(st, K0, ld, K0 + h->off_invd, X0, ld, T0, ld, np, count, cs, gs, tile));
   // K^-1 = L^-T L^-1 on the lower tiles, as an NT product of Xt = L^-T with itself (transposed in place; same sums in the same
   // k order as the TN form it replaces, so the values are unchanged)
-  HIPCHK(h, transpose_inplace(st, X0, ld, np, count, gs));
-  HIPCHK(h, launch_gemm(st, 0, 1, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, tile, count, gs, gs,
-                        gs));
+  if (kinv_tn()) {
+    HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, 64, count, gs, gs, gs));
+  } else {
+    HIPCHK(h, transpose_inplace(st, X0, ld, np, count, gs));
+    HIPCHK(h, launch_gemm(st, 0, 1, np, np, np, 1.0, X0, ld, X0, ld, 0.0, T0, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, tile, count, gs, gs,
+                          gs));
+  }
   TraceArgs ta{h->X.p, h->X.p, nullptr, T0, ld, K0 + h->off_alpha, K0 + h->off_alpha, -1.0, 1.0, (int)h->n, (int)h->n, h->d, 0.0, 1, h->gpartial.p,
                nullptr, 0, tiles};
   ta.cell_par = h->cellpar.p;
@@ -754,10 +765,14 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   if (h->tune.poison_workspace) HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0xff, sizeof(double) * h->np * ld, st));  // (see exact_gradient_batch)
   HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
   // K^-1 = X^T X on the lower tiles, into Tmp: NT product of Xt = L^-T (X transposed in place) with itself
-  HIPCHK(h, transpose_inplace(st, h->Xinv.p, ld, np));
-  h->have_linv = false;  // Xinv now holds L^-T: a later predict forms L^-1 again
-  HIPCHK(h, launch_gemm(st, 0, 1, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld,
-                        GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, h->tune.update_tile));
+  h->have_linv = false;  // (Xinv is not zeroed above its diagonal, or holds L^-T: a later predict forms L^-1 again)
+  if (kinv_tn()) {
+    HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, 64));
+  } else {
+    HIPCHK(h, transpose_inplace(st, h->Xinv.p, ld, np));
+    HIPCHK(h, launch_gemm(st, 0, 1, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld,
+                          GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, h->tune.update_tile));
+  }
   const int tiles = np / KM_T;
   const int width = 2 + h->d;
   if ((rc = ensure(h, h->partial, sizeof(double) * ((size_t)tiles * tiles * width + width)))) return rc;
