@@ -91,6 +91,7 @@ struct gprx_ctx {
   // batched exact factorisations (gprx_factorize_batch): `arena_slots` cell blocks, `cell_stride` doubles apart, each
   // [K (np + 64) x np | invD np x 64 | staged diagonal blocks np x 128 | alpha np]; parameter / result tables, one row per cell
   Buf arena, cellpar, cellres, garena, gpartial;  // garena: per cell [L^-1 | K^-1] for batched gradients
+  Buf apart;                                      // row-chunk partial sums of alpha_from_inverse
   Buf sarena;                                   // batched sparse models: one cell block per slot (sgpr_batch_layout)
   int sarena_slots = 0;
   double* spin = nullptr;  // pinned staging of the sparse batch: parameters up, reductions / gradients down
@@ -298,7 +299,9 @@ bool use_cell_kernel(const PotrfTuning& tune, int np, int cells) {
   return np <= 512 && cells >= 256;
 }
 
-int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookahead = true, bool capture = false) {
+// with_alpha = false: the backward substitution is left out -- the caller goes on to the gradient, which forms alpha from the
+// explicit inverse it builds anyway (alpha_from_inverse)
+int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookahead = true, bool capture = false, bool with_alpha = true) {
   const int np = (int)h->np;
   const int64_t ld = h->np;
   int rc;
@@ -343,9 +346,9 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   }
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
-  hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
+  if (with_alpha) hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, (const double*)h->Kmat.p, ld, beta, np, h->red.p, (int64_t)0, 0);
-  HIPCHK(h, trsv_lower(st, h->Kmat.p, ld, h->invD.p, h->alpha.p, np, true));
+  if (with_alpha) HIPCHK(h, trsv_lower(st, h->Kmat.p, ld, h->invD.p, h->alpha.p, np, true));
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[3], st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 64, h->red.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 72, h->info, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -547,7 +550,7 @@ int ensure_arena(gprx_handle h, int slots) {
   return GPRX_OK;
 }
 
-int exact_factorize_batch(gprx_handle h, int count, const int* units, const Theta* ts, double* lml_out, int* status_out) {
+int exact_factorize_batch(gprx_handle h, int count, const int* units, const Theta* ts, double* lml_out, int* status_out, bool with_alpha = true) {
   int rc;
   if ((rc = ensure_arena(h, count))) return rc;
   const int np = (int)h->np;
@@ -595,9 +598,9 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
                             2 * CELL_RES, &h->tune, 0, record_evt));
     }
     const double* beta = K0 + (int64_t)np * ld;
-    hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
+    if (with_alpha) hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
     hipLaunchKernelGGL(logdet_quad_kernel, dim3(cnt), dim3(256), 0, gs, (const double*)K0, ld, beta, np, cres, cs, CELL_RES);
-    HIPCHK(h, trsv_lower(gs, K0, ld, K0 + h->off_invd, K0 + h->off_alpha, np, true, cnt, cs));
+    if (with_alpha) HIPCHK(h, trsv_lower(gs, K0, ld, K0 + h->off_invd, K0 + h->off_alpha, np, true, cnt, cs));  // (else: exact_gradient_batch)
     return GPRX_OK;
   };
   if (groups == 1) {
@@ -692,7 +695,7 @@ bool kinv_tn() {
 // (L^-1 by bottom-up doubling, K^-1 = L^-T L^-1 on the lower tiles, one trace pass for all 2 + d derivatives) with
 // the cell index in the grid.  g: count x ntheta, constrained parameters (variance, lengthscales, noise); rows of
 // failed cells are left untouched.
-int exact_gradient_batch(gprx_handle h, int count, double* g) {
+int exact_gradient_batch(gprx_handle h, int count, double* g, bool form_alpha = false) {
   const int np = (int)h->np;
   const int64_t ld = h->np, cs = h->cell_stride, gs = 2 * (int64_t)h->np * h->np;
   int rc;
@@ -715,6 +718,10 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
   // (measured at 32 cells of N = 4096: 52.8 ms against 60.7 ms per batched objective + gradient)
   const int tile = h->tune.update_tile ? h->tune.update_tile : 64;
   HIPCHK(h, trtri_lower(st, K0, ld, K0 + h->off_invd, X0, ld, T0, ld, np, count, cs, gs, tile));
+  if (form_alpha) {  // the factorisation left the backward substitution out: alpha = X^T beta (T is free until the next product)
+    if ((rc = ensure(h, h->apart, sizeof(double) * (size_t)count * ((np + ALPHA_CHUNK - 1) / ALPHA_CHUNK) * np))) return rc;
+    HIPCHK(h, alpha_from_inverse(st, X0, ld, K0 + (int64_t)np * ld, h->apart.p, K0 + h->off_alpha, np, count, gs, cs, cs));
+  }
   // K^-1 = L^-T L^-1 on the lower tiles, as an NT product of Xt = L^-T with itself (transposed in place; same sums in the same
   // k order as the TN form it replaces, so the values are unchanged)
   if (kinv_tn()) {
@@ -755,7 +762,9 @@ int exact_gradient_batch(gprx_handle h, int count, double* g) {
 }
 
 // gradient of the LML w.r.t. constrained (variance, lengthscales[nlen], noise) -> g[0 .. nlen+1]
-int exact_gradient(gprx_handle h, const Theta& t, double* g) {
+// Enqueue the gradient's launches behind the factorisation on the handle's stream; `host` (2 + d doubles, alive until the
+// stream has been synchronised) receives the trace sums.  form_alpha: the factorisation left the backward substitution out.
+int exact_gradient_enqueue(gprx_handle h, const Theta& t, double* host, bool form_alpha) {
   const int np = (int)h->np;
   const int64_t ld = h->np;
   int rc;
@@ -764,7 +773,11 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   hipStream_t st = h->stream;
   if (h->tune.poison_workspace) HIPCHK(h, hipMemsetAsync(h->Xinv.p, 0xff, sizeof(double) * h->np * ld, st));  // (see exact_gradient_batch)
   HIPCHK(h, trtri_lower(st, h->Kmat.p, ld, h->invD.p, h->Xinv.p, ld, h->Tmp.p, ld, np));
-  // K^-1 = X^T X on the lower tiles, into Tmp: NT product of Xt = L^-T (X transposed in place) with itself
+  if (form_alpha) {
+    if ((rc = ensure(h, h->apart, sizeof(double) * (size_t)((np + ALPHA_CHUNK - 1) / ALPHA_CHUNK) * np))) return rc;
+    HIPCHK(h, alpha_from_inverse(st, h->Xinv.p, ld, h->Kmat.p + (int64_t)np * ld, h->apart.p, h->alpha.p, np));
+  }
+  // K^-1 = X^T X on the lower tiles, into Tmp
   h->have_linv = false;  // (Xinv is not zeroed above its diagonal, or holds L^-T: a later predict forms L^-1 again)
   if (kinv_tn()) {
     HIPCHK(h, launch_gemm(st, 1, 0, np, np, np, 1.0, h->Xinv.p, ld, h->Xinv.p, ld, 0.0, h->Tmp.p, ld, GEMM_C_LOWER | GEMM_A_UPPER | GEMM_B_LOWER, 64));
@@ -781,9 +794,11 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   HIPCHK(h, launch_trace(st, h->kid, with_form(ta, h), tiles * tiles));
   double* sums = h->partial.p + (size_t)tiles * tiles * width;
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, h->partial.p, tiles * tiles, width, sums);
-  std::vector<double> host(width);
-  HIPCHK(h, hipMemcpyAsync(host.data(), sums, sizeof(double) * width, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipMemcpyAsync(host, sums, sizeof(double) * width, hipMemcpyDeviceToHost, st));
+  return GPRX_OK;
+}
+// gradient of the LML w.r.t. constrained (variance, lengthscales[nlen], noise) -> g[0 .. nlen+1], from the synchronised trace sums
+void exact_gradient_collect(gprx_handle h, const double* host, double* g) {
   g[0] = 0.5 * host[0];
   if (h->ard) {
     for (int k = 0; k < h->d; ++k) g[1 + k] = 0.5 * host[2 + k];
@@ -793,9 +808,15 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
     g[1] = 0.5 * s;
   }
   g[1 + h->nlen] = 0.5 * host[1];
+}
+int exact_gradient(gprx_handle h, const Theta& t, double* g) {
+  std::vector<double> host(2 + h->d);
+  int rc;
+  if ((rc = exact_gradient_enqueue(h, t, host.data(), false))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  exact_gradient_collect(h, host.data(), g);
   return GPRX_OK;
 }
-
 
 // ---- sparse GP (SGPR) -----------------------------------------------------------------------------
 // Device restatement of gpflow SGPR._common_calculation / elbo / predict_f (oracle/sgpr.py) with
@@ -1442,7 +1463,7 @@ int gprx_destroy(gprx_handle h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
                  &h->pred, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs, &h->dZ,
-                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial, &h->sarena})
+                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial, &h->apart, &h->sarena})
     if (b->p && !b->borrowed) hipFree(b->p);
   if (h->bpin) hipHostFree(h->bpin);
   if (h->spin) hipHostFree(h->spin);
@@ -1541,8 +1562,21 @@ static int objective_impl(gprx_handle h, int unit, const double* theta, const do
   const Theta t = decode_theta(h, theta);
   const bool sparse = h->m != 0;
   double value = 0.0;  // LML (exact) or ELBO (sparse)
+  // exact model with gradient: ONE stream synchronisation for both halves, and alpha from the inverse the gradient builds (the
+  // 64 dependent launches of the backward substitution drop out of the evaluation); a non-PD matrix is reported by the
+  // factorisation's status as before (the gradient launches behind it are then wasted, not wrong: nothing is read back)
+  static const bool fused_eval = !(getenv("GPRX_FUSED_EVAL") && atoi(getenv("GPRX_FUSED_EVAL")) == 0);
+  const bool fused = !sparse && grad && fused_eval && !h->profiling;
+  std::vector<double> ghost(fused ? 2 + h->d : 0);
   if (sparse) {
     if ((rc = sgpr_factorize(h, unit, t, z, &value))) return rc;
+  } else if (fused) {
+    if ((rc = exact_factorize_enqueue(h, unit, t, true, false, false))) return rc;
+    if ((rc = exact_gradient_enqueue(h, t, ghost.data(), true))) {
+      hipStreamSynchronize(h->stream);
+      return rc;
+    }
+    if ((rc = exact_factorize_finish(h, &value))) return rc;
   } else {
     if ((rc = exact_factorize(h, unit, t, &value))) return rc;
   }
@@ -1553,6 +1587,8 @@ static int objective_impl(gprx_handle h, int unit, const double* theta, const do
     double* gz = sparse ? grad + h->ntheta : nullptr;
     if (sparse) {
       if ((rc = sgpr_gradient(h, unit, t, g.data(), gz))) return rc;
+    } else if (fused) {
+      exact_gradient_collect(h, ghost.data(), g.data());
     } else {
       if ((rc = exact_gradient(h, t, g.data()))) return rc;
     }
@@ -1750,12 +1786,14 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
       ts[i] = decode_theta(h, theta + (int64_t)i * h->ntheta);
     }
     std::vector<double> lml(count);
-    const int frc = exact_factorize_batch(h, count, units, ts.data(), lml.data(), nullptr);
+    static const bool fused_eval = !(getenv("GPRX_FUSED_EVAL") && atoi(getenv("GPRX_FUSED_EVAL")) == 0);
+    const bool form_alpha = grads && fused_eval;  // (as gprx_objective: alpha from the gradient's inverse, same kernels -> same bits)
+    const int frc = exact_factorize_batch(h, count, units, ts.data(), lml.data(), nullptr, !form_alpha);
     if (frc != GPRX_OK && frc != GPRX_ENOTPD) return frc;
     for (int i = 0; i < count; ++i) losses[i] = -(lml[i] + log_prior(h, ts[i], mask));
     if (grads) {
       std::vector<double> g((size_t)count * h->ntheta, 0.0);
-      if ((rc = exact_gradient_batch(h, count, g.data()))) return rc;
+      if ((rc = exact_gradient_batch(h, count, g.data(), form_alpha))) return rc;
       for (int i = 0; i < count; ++i) {
         double* gi = grads + (int64_t)i * gw;
         if (h->slot_ok[i]) {

@@ -107,6 +107,49 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ 
   if (tid < NB) b[j * NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
+// ---- alpha = L^-T beta from the explicit inverse X = L^-1 (the gradient has just built it): alpha_j = sum_{i >= j} X[i][j] beta_i.
+// One pass over the lower tiles of X in two launches instead of the 64 dependent launches of the backward substitution (0.27 ms of
+// a lone N = 4096 evaluation).  Deterministic: workgroup (column block, row chunk) sums its rows in a fixed order (thread group
+// `grp` takes rows grp, grp + 4, ...; the four groups are added in order), alpha_final adds the chunks in order.
+// grid = (np / 64, chunks, cells); part: chunks x np doubles per cell.
+constexpr int ALPHA_CHUNK = 512;  // rows per workgroup
+__global__ __launch_bounds__(256) void alpha_partial_kernel(const double* __restrict__ X, int64_t ldx, const double* __restrict__ beta,
+                                                            double* __restrict__ part, int np, int64_t cs_x, int64_t cs_b, int64_t cs_p) {
+  __shared__ double red[4][NB];
+  X += (int64_t)blockIdx.z * cs_x;
+  beta += (int64_t)blockIdx.z * cs_b;
+  part += (int64_t)blockIdx.z * cs_p;
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * NB;
+  int r0 = blockIdx.y * ALPHA_CHUNK;
+  const int r1 = min(r0 + ALPHA_CHUNK, np);
+  if (r0 < j0) r0 = j0;  // (tiles above the diagonal hold nothing; the diagonal block has explicit zeros above its diagonal)
+  double s = 0.0;
+  for (int i = r0 + grp; i < r1; i += 4) s = __builtin_fma(X[(int64_t)i * ldx + j0 + c], beta[i], s);
+  red[grp][c] = s;
+  __syncthreads();
+  if (threadIdx.x < NB) part[(int64_t)blockIdx.y * np + j0 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+__global__ __launch_bounds__(256) void alpha_final_kernel(const double* __restrict__ part, int chunks, double* __restrict__ alpha, int np,
+                                                          int64_t cs_p, int64_t cs_a) {
+  part += (int64_t)blockIdx.y * cs_p;
+  alpha += (int64_t)blockIdx.y * cs_a;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= np) return;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * np + j];
+  alpha[j] = s;
+}
+// part: cells * ceil(np / ALPHA_CHUNK) * np doubles
+inline hipError_t alpha_from_inverse(hipStream_t st, const double* X, int64_t ldx, const double* beta, double* part, double* alpha, int np,
+                                     int cells = 1, int64_t cs_x = 0, int64_t cs_b = 0, int64_t cs_a = 0) {
+  const int chunks = (np + ALPHA_CHUNK - 1) / ALPHA_CHUNK;
+  const int64_t cs_p = (int64_t)chunks * np;
+  hipLaunchKernelGGL(alpha_partial_kernel, dim3(np / NB, chunks, cells), dim3(256), 0, st, X, ldx, beta, part, np, cs_x, cs_b, cs_p);
+  hipLaunchKernelGGL(alpha_final_kernel, dim3((np + 255) / 256, cells), dim3(256), 0, st, (const double*)part, chunks, alpha, np, cs_p, cs_a);
+  return hipGetLastError();
+}
+
 inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* b, int np, bool transpose,
                              int batch = 1, int64_t cs = 0) {
   const int nblocks = np / NB;
