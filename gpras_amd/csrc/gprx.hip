@@ -1793,7 +1793,14 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
     for (int i = 0; i < count; ++i) losses[i] = -(lml[i] + log_prior(h, ts[i], mask));
     if (grads) {
       std::vector<double> g((size_t)count * h->ntheta, 0.0);
-      if ((rc = exact_gradient_batch(h, count, g.data(), form_alpha))) return rc;
+      if ((rc = exact_gradient_batch(h, count, g.data(), form_alpha))) {
+        if (form_alpha)  // (the slots hold factors without their alpha: nothing may predict from them)
+          for (int i = 0; i < count; ++i) {
+            h->slot_ok[i] = 0;
+            h->slot_unit[i] = -1;
+          }
+        return rc;
+      }
       for (int i = 0; i < count; ++i) {
         double* gi = grads + (int64_t)i * gw;
         if (h->slot_ok[i]) {
