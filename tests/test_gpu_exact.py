@@ -279,3 +279,30 @@ def test_gradient_does_not_depend_on_old_workspace_contents(lib, n):
     assert np.all(np.isfinite(out[1][1])) and np.all(np.isfinite(out[1][3]))
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.parametrize("kernel,noise", [("RBF", 0.05), ("RBF", 2e-6), ("Matern32", 1e-4)])
+def test_alpha_from_the_gradients_inverse_agrees_with_backward_substitution(lib, kernel, noise):
+    """An evaluation WITH a gradient forms alpha = X^T beta from the inverse it builds (solve.h alpha_from_inverse), a plain
+    factorisation by backward substitution: the predictive means that follow agree far inside the 1e-8 of the boundary, also
+    near the noise floor where K is worst conditioned."""
+    n, d, ns = 700, 5, 257
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=ns, config=1, unit=n)
+    h = make_handle(lib, n, d, kernel, False, x, y)
+    try:
+        theta = pack_theta(1.2, 0.9, noise)
+        loss, grad = C.c_double(), np.zeros(theta.size)
+        check(lib.gprx_objective(h, 0, ptr(theta), None, ALL, C.byref(loss), ptr(grad)), h)
+        m1, v1 = np.zeros(ns), np.zeros(ns)
+        check(lib.gprx_predict(h, ptr(xs), ns, ptr(m1), ptr(v1), 1), h)
+        loss2 = C.c_double()
+        check(lib.gprx_factorize(h, 0, ptr(theta), None, ALL, C.byref(loss2)), h)
+        m2, v2 = np.zeros(ns), np.zeros(ns)
+        check(lib.gprx_predict(h, ptr(xs), ns, ptr(m2), ptr(v2), 1), h)
+        assert loss.value == loss2.value
+        assert np.max(np.abs(m1 - m2)) <= 1e-9 * np.max(np.abs(m2))
+        assert np.array_equal(v1, v2)  # (the variance does not involve alpha)
+        ref_mean, _ = oex.predict(kernel, x, y[:, 0], 1.2, 0.9, noise, xs, True)
+        assert np.max(np.abs(m1 - ref_mean)) <= 1e-8 * np.max(np.abs(ref_mean))
+    finally:
+        lib.gprx_destroy(h)
