@@ -92,6 +92,8 @@ struct gprx_ctx {
   // [K (np + 64) x np | invD np x 64 | staged diagonal blocks np x 128 | alpha np]; parameter / result tables, one row per cell
   Buf arena, cellpar, cellres, garena, gpartial;  // garena: per cell [L^-1 | K^-1] for batched gradients
   Buf apart;                                      // row-chunk partial sums of alpha_from_inverse
+  hipEvent_t kev[2] = {nullptr, nullptr};         // profiling: events around the kernel-build launch
+  double kmat_ms = 0.0, kmat_bytes = 0.0;
   Buf sarena;                                   // batched sparse models: one cell block per slot (sgpr_batch_layout)
   int sarena_slots = 0;
   double* spin = nullptr;  // pinned staging of the sparse batch: parameters up, reductions / gradients down
@@ -330,7 +332,18 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   }
   KmatArgs ka{h->X.p, h->X.p, h->invls.p, h->Kmat.p, ld, (int)h->n, (int)h->n, h->d, np, np, t.variance, t.noise, 1, 1.0,
               capture ? h->gparams : nullptr, 0};
+  if (h->profiling && !capture) {
+    if (!h->kev[0]) {
+      HIPCHK(h, hipEventCreate(&h->kev[0]));
+      HIPCHK(h, hipEventCreate(&h->kev[1]));
+    }
+    HIPCHK(h, hipEventRecord(h->kev[0], st));
+  }
   HIPCHK(h, launch_kmat(st, h->kid, with_form(ka, h)));
+  if (h->profiling && !capture) {
+    HIPCHK(h, hipEventRecord(h->kev[1], st));
+    h->kmat_bytes = 8.0 * KM_T * KM_T * (double)(np / KM_T) * (np / KM_T + 1) / 2;  // the lower 64 x 64 tiles
+  }
   hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(64), dim3(256), 0, st, h->Kmat.p + (int64_t)np * ld, ld, h->Y.p + (int64_t)unit * h->np,
                      (int)h->n, np, NB);
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[1], st));
@@ -433,6 +446,10 @@ void summarize_profile(gprx_handle h) {
     hipEventElapsedTime(&ms, h->prof.pool[mk.first], h->prof.pool[mk.first + 1]);
     strip_ms += ms;
     strip_flops += mk.second;
+  }
+  if (h->kev[0]) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->kev[0], h->kev[1]) == hipSuccess) h->kmat_ms = ms;
   }
   h->prof_out[5] = strip_ms;
   h->prof_out[6] = (double)h->prof.strip_marks.size();
@@ -585,7 +602,18 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
     ka.cell_par = cpar;
     ka.out_stride = cs;
+    if (h->profiling) {
+      if (!h->kev[0]) {
+        HIPCHK(h, hipEventCreate(&h->kev[0]));
+        HIPCHK(h, hipEventCreate(&h->kev[1]));
+      }
+      HIPCHK(h, hipEventRecord(h->kev[0], gs));
+    }
     HIPCHK(h, launch_kmat(gs, h->kid, with_form(ka, h), cnt));
+    if (h->profiling) {
+      HIPCHK(h, hipEventRecord(h->kev[1], gs));
+      h->kmat_bytes = 8.0 * KM_T * KM_T * (double)(np / KM_T) * (np / KM_T + 1) / 2 * cnt;
+    }
     hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
@@ -1470,6 +1498,8 @@ int gprx_destroy(gprx_handle h) {
   for (auto& ev : h->bev)
     if (ev) hipEventDestroy(ev);
   if (h->stagger_evt) hipEventDestroy(h->stagger_evt);
+  for (auto& ev : h->kev)
+    if (ev) hipEventDestroy(ev);
   if (h->info) hipFree(h->info);
   if (h->pin) hipHostFree(h->pin);
   if (h->gparams) hipFree(h->gparams);
@@ -1767,6 +1797,13 @@ int gprx_set_profiling(gprx_handle h, int enabled) {
 int gprx_last_profile(gprx_handle h, double* out8) {
   if (!h || !out8) return fail(h, GPRX_EINVAL, "null argument");
   for (int i = 0; i < 8; ++i) out8[i] = h->prof_out[i];
+  return GPRX_OK;
+}
+
+int gprx_last_kernel_build(gprx_handle h, double* ms, double* bytes) {
+  if (!h || !ms || !bytes) return fail(h, GPRX_EINVAL, "null argument");
+  *ms = h->kmat_ms;
+  *bytes = h->kmat_bytes;
   return GPRX_OK;
 }
 

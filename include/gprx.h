@@ -151,6 +151,11 @@ int gprx_last_timings(gprx_handle h, double* ms4);
  *                           prefetch) total ms, launches, algorithmic flops] of the last exact factorisation(s). */
 int gprx_set_profiling(gprx_handle h, int enabled);
 int gprx_last_profile(gprx_handle h, double* out8);
+/* The kernel-build launch (kmat_kernel: every 64 x 64 tile on or below the diagonal, all cells of a batch in one launch) of the
+ * last PROFILED exact factorisation: duration by HIP events around that launch, and the bytes it writes (8 * 64 * 64 * lower tiles
+ * * cells) -- bench.py's kernel_build_hbm figure (north_star: "HBM GB/s on the kernel build"; reference: the K(X, X) inside
+ * every training_loss, /root/reference/gpras/gpr.py:153-155). */
+int gprx_last_kernel_build(gprx_handle h, double* ms, double* bytes);
 
 /* ---- batched small problems ------------------------------------------------------- */
 /* Evaluate loss (+ gradient) for `count` units in one call: units[i] with theta row i
