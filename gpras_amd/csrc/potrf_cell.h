@@ -80,6 +80,146 @@ __device__ __forceinline__ int cell_diag(double* __restrict__ Ajj, int64_t lda, 
   return c.bad;
 }
 
+// Tiles (i0 .. i0+ni-1, j), all below the diagonal tile, in ONE pass: C_t <- (C_t - sum_{c<j} L(i,c) L(j,c)^T) L(j,j)^-T.  The
+// update sum as dag_panel<false> forms it (same steps, same accumulators); the updated tile then goes from the accumulator layout
+// straight into the A stage image and is multiplied by the inverse (B image, loaded once per call) exactly as dag_panel<true>
+// does with the tile it re-reads from memory -- same operands, same products: the factor is the two-pass kernel's bit for bit,
+// with one store and one load of every tile less (8.7 of ~44 MB per N = 1024 cell).
+__device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int ni, int j, double* __restrict__ smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
+  const unsigned ldb = (unsigned)p.lda * 8u;
+  double* sA = smem;
+  double* sB = smem + NB * NB;
+  const int lrow0 = tid >> 5, c32 = tid & 31;
+  const unsigned off_ld = (unsigned)lrow0 * ldb + (unsigned)c32 * 16u;
+  const unsigned off_ld_inv = (unsigned)lrow0 * (NB * 8u) + (unsigned)c32 * 16u;
+  const int st_img = (c32 >> 3) * (NB * GEMM_BK), st_cc = c32 & 7;
+  const unsigned off_cd = (unsigned)(wm * 32 + g) * ldb + (unsigned)(wn * 32 + r) * 8u;
+  const int swz = kc_swz(r);
+  const int nsteps = j * ni;
+  const double* Brow = p.A + (int64_t)j * NB * p.lda;
+  d4 acc[DAG_NI][2][2];
+#pragma unroll
+  for (int t = 0; t < DAG_NI; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = d4{0.0, 0.0, 0.0, 0.0};
+  d2 ra[8], rb[8];
+  double cold[2][2][4];
+  auto request_c = [&](int t) {
+    const __amdgpu_buffer_rsrc_t rc = dag_rsrc(p.A + (int64_t)(i0 + t) * NB * p.lda + (int64_t)j * NB);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cold[a][b][q] = ld1_sc1<false>(rc, off_cd, (unsigned)(a * 16 + 4 * q) * ldb + (unsigned)b * 128u);
+  };
+  auto request = [&](int step) {
+    const int blk = step / ni, t = step - blk * ni;
+    const __amdgpu_buffer_rsrc_t rsa = dag_rsrc(p.A + (int64_t)(i0 + t) * NB * p.lda + (int64_t)blk * NB);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ra[e] = ld2_sc1<false>(rsa, off_ld, (unsigned)(8 * e) * ldb);
+    if (t == 0) {
+      const __amdgpu_buffer_rsrc_t rsb = dag_rsrc(Brow + (int64_t)blk * NB);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb[e] = ld2_sc1<false>(rsb, off_ld, (unsigned)(8 * e) * ldb);
+    }
+  };
+  auto request_inverse = [&] {
+    const __amdgpu_buffer_rsrc_t rsb = dag_rsrc(p.inv_diag + (int64_t)j * NB * NB);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rb[e] = ld2_sc1<false>(rsb, off_ld_inv, (unsigned)(8 * e) * (NB * 8u));
+  };
+  auto publish = [&](bool with_a, bool with_b) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = lrow0 + 8 * e;
+      const int slot = st_img + row * GEMM_BK + ((st_cc ^ kc_swz(row)) * 2);
+      if (with_a) *reinterpret_cast<d2*>(sA + slot) = ra[e];
+      if (with_b) *reinterpret_cast<d2*>(sB + slot) = rb[e];
+    }
+  };
+  if (nsteps > 0) request(0);
+  for (int step = 0; step < nsteps; ++step) {
+    const int blk = step / ni, t = step - blk * ni;
+    lds_barrier();
+    publish(true, t == 0);
+    lds_barrier();
+    if (step + 1 < nsteps) {
+      request(step + 1);
+    } else {
+      request_c(0);  // under the last step's MFMAs
+    }
+#pragma unroll
+    for (int tt = 0; tt < DAG_NI; ++tt)
+      if (tt == t) dag_mma64(acc[tt], sA, sB, wm, wn, g, r, swz);
+  }
+  if (nsteps == 0) request_c(0);
+  request_inverse();  // (not under the MFMAs: with the operand registers of the last step still live it spilled)
+  lds_barrier();  // every wave has finished reading the last step's images
+  publish(false, true);  // the inverse becomes the B image
+#pragma unroll
+  for (int t = 0; t < DAG_NI; ++t) {
+    if (t < ni) {
+      // the updated tile (C + (-1) * sum, one rounding, as gemm_f64) -> A stage image
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = wm * 32 + a * 16 + g + 4 * q, col = wn * 32 + b * 16 + r;
+            const double v = __builtin_fma(1.0, cold[a][b][q], -1.0 * acc[t][a][b][q]);
+            sA[(col >> 4) * (NB * GEMM_BK) + row * GEMM_BK + ((((col & 15) >> 1) ^ kc_swz(row)) * 2) + (col & 1)] = v;
+          }
+      lds_barrier();
+      if (t + 1 < ni) request_c(t + 1);
+      d4 (&u)[2][2] = acc[t];  // (the sum has gone into the image: its registers take the product)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) u[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+      dag_mma64(u, sA, sB, wm, wn, g, r, swz);
+      const __amdgpu_buffer_rsrc_t rc = dag_rsrc(p.A + (int64_t)(i0 + t) * NB * p.lda + (int64_t)j * NB);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) st1_sc1<false>(rc, off_cd, u[a][b][q], (unsigned)(a * 16 + 4 * q) * ldb + (unsigned)b * 128u);
+      lds_barrier();  // (the A image is free for the next tile)
+    }
+  }
+}
+
+// FUSED (default): per block column the diagonal tile is updated alone, factored, and every group of tiles below it is updated and
+// solved in one pass (cell_panel_fused); FUSED = false: the two-pass form (update every tile, factor, solve every tile).
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void potrf_cell_kernel_t(CellArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[DAG_SMEM];
+  const int64_t off = (int64_t)blockIdx.x * p.cs;
+  const TileCtx tc{p.A + off, p.lda, p.inv_diag + off};
+  int first_bad = 0;
+  for (int j = 0; j < p.T; ++j) {
+    if (j > 0) {
+      dag_panel<false, false>(tc, j, 1, j, 0, j, smem);  // the diagonal tile's update
+      __syncthreads();
+    }
+    const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
+    if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
+    __syncthreads();
+    for (int i0 = j + 1; i0 < p.R; i0 += DAG_NI) {
+      const int ni = p.R - i0 < DAG_NI ? p.R - i0 : DAG_NI;
+      cell_panel_fused(tc, i0, ni, j, smem);
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0 && first_bad > 0) atomicCAS(p.info + (int64_t)blockIdx.x * p.info_stride, 0, p.col_base + first_bad);
+}
+
 __global__ __launch_bounds__(256, 2) void potrf_cell_kernel(CellArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[DAG_SMEM];
   const int64_t off = (int64_t)blockIdx.x * p.cs;
@@ -118,7 +258,11 @@ inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, in
   a.cs = cs;
   a.info_stride = info_stride;
   a.col_base = col_base;
-  hipLaunchKernelGGL(potrf_cell_kernel, dim3(batch), dim3(256), 0, st, a);
+  static const bool two_pass = getenv("GPRX_CELL_TWO_PASS") && atoi(getenv("GPRX_CELL_TWO_PASS")) != 0;
+  if (two_pass)
+    hipLaunchKernelGGL(potrf_cell_kernel, dim3(batch), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(potrf_cell_kernel_t<true>, dim3(batch), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

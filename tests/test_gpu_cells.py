@@ -1,0 +1,135 @@
+"""The one-workgroup-per-cell Cholesky for many small matrices (gpras_amd/csrc/potrf_cell.h; "cell_kernel" = 1 forces it, -1
+forbids it, default: N <= 512 with >= 256 cells, N <= 1024 with >= 512 cells) through gprx_factorize_batch /
+gprx_objective_batch: against the batched launch sequence (same tile products, another summation grouping: equal to rounding),
+against the oracle, with a failing cell, and the two-pass form of the kernel bit for bit."""
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gpras_amd import _lib
+from gpras_amd._lib import check, ptr
+from gpras_amd.synth import make_regression
+from oracle import exact as oex
+from oracle import kernels as okn
+from oracle import transforms as otr
+
+pytestmark = pytest.mark.gpu
+ALL = _lib.TRAIN_VARIANCE | _lib.TRAIN_LENGTHSCALE | _lib.TRAIN_NOISE
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def handle(lib, n, d, kernel, x, y, cell_kernel):
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS[kernel], 0, C.byref(h)))
+    check(lib.gprx_set_handle_tuning(h, b"cell_kernel", cell_kernel), h)
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), y.shape[1]), h)
+    return h
+
+
+def thetas_for(x, cells, seed):
+    base = np.array(otr.unconstrain(1.0, float(np.mean(np.abs(x))), 0.5), dtype=np.float64)
+    return np.ascontiguousarray(base[None, :] + np.random.default_rng(seed).uniform(-0.2, 0.2, size=(cells, 3)))
+
+
+@pytest.mark.parametrize("kernel,n,d,cells", [("RBF", 64, 2, 5), ("RBF", 200, 3, 40), ("Matern52", 333, 4, 12), ("Matern12", 512, 8, 9), ("RBF", 1000, 5, 6),
+                                              ("Matern32", 1024, 8, 4)])
+def test_cell_kernel_against_launch_sequence_and_oracle(lib, kernel, n, d, cells):
+    ns = 40
+    x, y, xs = make_regression(n, d, n_outputs=cells, n_test=ns, config=2, unit=n)
+    thetas = thetas_for(x, cells, n)
+    units = np.arange(cells, dtype=np.int32)
+    got = {}
+    for mode in (-1, 1):
+        h = handle(lib, n, d, kernel, x, y, mode)
+        try:
+            losses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
+            check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), ALL, ptr(losses), ptr(status)), h)
+            assert not status.any()
+            preds = []
+            for c in (0, cells - 1):
+                check(lib.gprx_select_slot(h, c), h)
+                mean, var = np.zeros(ns), np.zeros(ns)
+                check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(var), 1), h)
+                preds.append((mean, var))
+            glosses, grads = np.zeros(cells), np.zeros((cells, 3))
+            check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, ALL, ptr(glosses), ptr(grads)), h)
+            got[mode] = (losses, preds, glosses, grads)
+        finally:
+            lib.gprx_destroy(h)
+    (l0, p0, gl0, g0), (l1, p1, gl1, g1) = got[-1], got[1]
+    assert np.max(np.abs(l1 - l0) / np.abs(l0)) <= 1e-13
+    assert np.array_equal(gl1, l1) or np.max(np.abs(gl1 - l1) / np.abs(l1)) <= 1e-15  # (objective = factorisation + prior of nothing)
+    assert np.max(np.abs(g1 - g0)) <= 1e-9 * np.max(np.abs(g0))
+    for (m0, v0), (m1, v1) in zip(p0, p1):
+        assert np.max(np.abs(m1 - m0)) <= 1e-11 * np.max(np.abs(m0)) and np.max(np.abs(v1 - v0) / v0) <= 1e-11
+    for c, (mean, var) in zip((0, cells - 1), p1):
+        ref = oex.loss(kernel, x, y[:, c], float(thetas[c, 0]), float(thetas[c, 1]), float(thetas[c, 2]))
+        assert abs(l1[c] - ref) <= 1e-9 * abs(ref)
+        v, l, s = otr.constrain(thetas[c, 0], thetas[c, 1], thetas[c, 2])
+        rm, rv = oex.predict(kernel, x, y[:, c], float(v), float(l), float(s), xs)
+        assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
+
+
+def test_cell_kernel_reports_a_failing_cell_alone(lib):
+    n, d = 256, 3
+    x, y, _ = make_regression(n, d, config=1, unit=1)
+    x[1::2] = x[0::2]  # duplicated inputs: singular without the noise term
+    h = handle(lib, n, d, "RBF", x, y, 1)
+    try:
+        good = np.concatenate([[otr.unconstrain(1.0, 0.9, 0.1)[0]], [otr.unconstrain(1.0, 0.9, 0.1)[1]], [otr.unconstrain(1.0, 0.9, 0.1)[2]]])
+        bad = good.copy()
+        bad[0], bad[1], bad[-1] = 40.0, 50.0, -800.0
+        thetas = np.ascontiguousarray(np.stack([good, bad, good, good]))
+        units = np.zeros(4, dtype=np.int32)
+        losses, status = np.zeros(4), np.zeros(4, dtype=np.int32)
+        rc = lib.gprx_factorize_batch(h, 4, ptr(units), ptr(thetas), ALL, ptr(losses), ptr(status))
+        ref = oex.loss("RBF", x, y[:, 0], float(good[0]), float(good[1]), float(good[2]))
+        assert abs(losses[0] - ref) <= 1e-9 * abs(ref) and losses[2] == losses[0] and losses[3] == losses[0]
+        if rc == _lib.GPRX_ENOTPD:
+            assert status[1] == _lib.GPRX_ENOTPD and not status[[0, 2, 3]].any() and np.isnan(losses[1])
+            assert lib.gprx_select_slot(h, 1) == _lib.GPRX_ESTATE
+        else:
+            assert rc == _lib.GPRX_OK
+    finally:
+        lib.gprx_destroy(h)
+
+
+TWO_PASS = r"""
+import ctypes as C, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from gpras_amd import _lib
+from gpras_amd._lib import check, ptr
+from gpras_amd.synth import make_regression
+from oracle import transforms as otr
+lib = _lib.load()
+n, d, cells = 700, 4, 10
+x, y, _ = make_regression(n, d, n_outputs=cells, n_test=4, config=2, unit=n)
+base = np.array(otr.unconstrain(1.0, float(np.mean(np.abs(x))), 0.5), dtype=np.float64)
+thetas = np.ascontiguousarray(base[None, :] + np.random.default_rng(1).uniform(-0.2, 0.2, size=(cells, 3)))
+units = np.arange(cells, dtype=np.int32)
+h = C.c_void_p()
+check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h)))
+check(lib.gprx_set_handle_tuning(h, b"cell_kernel", 1), h)
+check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+losses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
+check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(losses), ptr(status)), h)
+lib.gprx_destroy(h)
+print(json.dumps([float.hex(v) for v in losses]))
+"""
+
+
+def test_fused_cell_kernel_equals_its_two_pass_form_bit_for_bit():
+    """cell_panel_fused (update and solve of a tile in one pass) performs the products of the two-pass kernel on the same operands."""
+    outs = []
+    for two_pass in ("0", "1"):
+        res = subprocess.run([sys.executable, "-c", TWO_PASS.format(root=ROOT)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, GPRX_CELL_TWO_PASS=two_pass))
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
