@@ -195,6 +195,72 @@ __device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int n
   }
 }
 
+// The diagonal tile's update alone: A(j,j) -= sum_{c<j} L(j,c) L(j,c)^T.  Both operands of a step are the SAME block, so one
+// block load per step feeds both images' reads, and with one accumulator tile there are registers for two loads in flight (the
+// general panel's one-step-ahead prefetch left a memory round trip exposed in every step of this short dependent pass: 120 steps
+// per N = 1024 cell).  Same products in the same order as dag_panel<false> on this tile: bit-identical.
+__device__ __forceinline__ void cell_diag_update(const TileCtx& p, int j, double* __restrict__ smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
+  const unsigned ldb = (unsigned)p.lda * 8u;
+  double* sA = smem;
+  const int lrow0 = tid >> 5, c32 = tid & 31;
+  const unsigned off_ld = (unsigned)lrow0 * ldb + (unsigned)c32 * 16u;
+  const int st_img = (c32 >> 3) * (NB * GEMM_BK), st_cc = c32 & 7;
+  const unsigned off_cd = (unsigned)(wm * 32 + g) * ldb + (unsigned)(wn * 32 + r) * 8u;
+  const int swz = kc_swz(r);
+  const double* Brow = p.A + (int64_t)j * NB * p.lda;
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+  d2 r0[8], r1[8];
+  auto request = [&](d2 (&v)[8], int blk) {
+    const __amdgpu_buffer_rsrc_t rs = dag_rsrc(Brow + (int64_t)blk * NB);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ld2_sc1<false>(rs, off_ld, (unsigned)(8 * e) * ldb);
+  };
+  auto publish = [&](const d2 (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = lrow0 + 8 * e;
+      *reinterpret_cast<d2*>(sA + st_img + row * GEMM_BK + ((st_cc ^ kc_swz(row)) * 2)) = v[e];
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rc = dag_rsrc(Brow + (int64_t)j * NB);
+  double cold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cold[a][b][q] = ld1_sc1<false>(rc, off_cd, (unsigned)(a * 16 + 4 * q) * ldb + (unsigned)b * 128u);
+  request(r0, 0);
+  if (j > 1) request(r1, 1);
+  for (int k = 0; k < j; k += 2) {
+    lds_barrier();
+    publish(r0);
+    lds_barrier();
+    if (k + 2 < j) request(r0, k + 2);
+    dag_mma64(acc, sA, sA, wm, wn, g, r, swz);
+    if (k + 1 < j) {
+      lds_barrier();
+      publish(r1);
+      lds_barrier();
+      if (k + 3 < j) request(r1, k + 3);
+      dag_mma64(acc, sA, sA, wm, wn, g, r, swz);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        st1_sc1<false>(rc, off_cd, __builtin_fma(1.0, cold[a][b][q], -1.0 * acc[a][b][q]), (unsigned)(a * 16 + 4 * q) * ldb + (unsigned)b * 128u);
+}
+
 // FUSED (default): per block column the diagonal tile is updated alone, factored, and every group of tiles below it is updated and
 // solved in one pass (cell_panel_fused); FUSED = false: the two-pass form (update every tile, factor, solve every tile).
 template <bool FUSED>
@@ -205,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void potrf_cell_kernel_t(CellArgs p) {
   int first_bad = 0;
   for (int j = 0; j < p.T; ++j) {
     if (j > 0) {
-      dag_panel<false, false>(tc, j, 1, j, 0, j, smem);  // the diagonal tile's update
+      cell_diag_update(tc, j, smem);
       __syncthreads();
     }
     const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
