@@ -64,6 +64,46 @@ def test_c2_n4096_32_cell_batch_loss_gradient_predict(lib):
         lib.gprx_destroy(h)
 
 
+def test_n1024_512_cells_per_launch_by_both_schedules_against_the_oracle(lib):
+    """north_star's N = 1k at the size bench.py runs it (512 cells per batched call): the default there is the one-workgroup-per-cell
+    kernel (potrf_cell.h); the launch sequence beside it; sampled cells against the oracle (loss 1e-9, predictions 1e-8)."""
+    n, d, cells, ns = 1024, 8, 512, 300
+    x, y, xs = make_regression(n, d, n_outputs=cells, n_test=ns, config=2, unit=500)
+    rng = np.random.default_rng(9)
+    base = np.array(otr.unconstrain(1.0, float(np.mean(np.abs(x))), 0.7), dtype=np.float64)
+    thetas = np.ascontiguousarray(base[None, :] + rng.uniform(-0.25, 0.25, size=(cells, 3)))
+    units = np.arange(cells, dtype=np.int32)
+    sample = (0, 101, 256, 511)
+    out = {}
+    for knob in (0, -1):  # default (cell kernel at this size), launch sequence
+        h = C.c_void_p()
+        check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+        check(lib.gprx_set_handle_tuning(h, b"cell_kernel", knob), h)
+        check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+        try:
+            losses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
+            check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(losses), ptr(status)), h)
+            assert not status.any()
+            preds = {}
+            for c in sample:
+                check(lib.gprx_select_slot(h, c), h)
+                mean, var = np.zeros(ns), np.zeros(ns)
+                check(lib.gprx_predict(h, ptr(xs), ns, ptr(mean), ptr(var), 1), h)
+                preds[c] = (mean, var)
+            out[knob] = (losses, preds)
+        finally:
+            lib.gprx_destroy(h)
+    assert np.max(np.abs(out[0][0] - out[-1][0]) / np.abs(out[-1][0])) <= 1e-13
+    for c in sample:
+        ref = oex.loss("RBF", x, y[:, c], float(thetas[c, 0]), float(thetas[c, 1]), float(thetas[c, 2]))
+        v, l, s = otr.constrain(thetas[c, 0], thetas[c, 1], thetas[c, 2])
+        rm, rv = oex.predict("RBF", x, y[:, c], float(v), float(l), float(s), xs)
+        for knob in (0, -1):
+            assert abs(out[knob][0][c] - ref) <= 1e-9 * abs(ref), (knob, c)
+            mean, var = out[knob][1][c]
+            assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8, (knob, c)
+
+
 def test_c3_n4096_matern52_ard_lbfgs_against_the_oracle_driver():
     n, d = 4096, 8
     x, y, xs = make_regression(n, d, n_outputs=1, n_test=500, config=3, unit=1)
