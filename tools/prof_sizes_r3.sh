@@ -13,6 +13,6 @@ run() {  # tag, env assignment, command...
 run r03_n4096_single GPRX_X=0 python3 tools/large_probe.py 4096 8
 run r03_n4096_single_tile_dag GPRX_DAG=1 python3 tools/large_probe.py 4096 8
 run r03_n16384_single GPRX_X=0 python3 tools/large_probe.py 16384 12
-run r03_n1024_batched GPRX_X=0 python3 tools/batch_n1024.py 1024 512
+run r03_n1024_batched GPRX_CELL_KERNEL=-1 python3 tools/batch_n1024.py 1024 512
 run r03_n1024_batched_cell_kernel GPRX_CELL_KERNEL=1 python3 tools/batch_n1024.py 1024 512
 run r03_n512_batched_cell_kernel GPRX_X=0 python3 tools/batch_n1024.py 512 512
