@@ -139,7 +139,7 @@ def main():
     # loaded) and torch.distributed launches the collective's bootstrap.  There is no automatic fall-back from one to the other:
     # once libgprx has initialised ROCm's HIP runtime, torch finds no GPU in the same process (measured: "No HIP GPUs are
     # available") -- a failed torch-free rendezvous ends every rank with a message instead.
-    torch = dist = comm = None
+    torch = dist = comm = fx = None
     comm_error = ""
     launcher = "single process"
     use_torch = distributed and os.environ.get("GPRX_BENCH_TORCH") == "1"
@@ -169,6 +169,8 @@ def main():
 
         prefix = default_id_prefix()
         try:
+            if os.environ.get("GPRX_BENCH_FORCE_COMM_FAILURE") == "1":  # (testing hook for the last-resort path below)
+                raise RuntimeError("forced by GPRX_BENCH_FORCE_COMM_FAILURE")
             # (with a process group the id travels through it; without, through files)
             comm = Communicator.bootstrap(device, rank, world, id_file=None if use_torch else prefix)
             if not use_torch:
@@ -186,9 +188,17 @@ def main():
                 comm.close()
             comm, comm_error = None, comm_error or "another rank could not create its communicator"
         if comm is None and not use_torch:
-            sys.stderr.write(f"bench.py rank {rank}: the communicator could not be created on every rank ({comm_error}); "
-                             "GPRX_BENCH_TORCH=1 selects the torch.distributed launch path\n")
-            sys.exit(3)
+            # last resort (GPRX_BENCH_NO_FILE_EXCHANGE=1: give up with exit code 3 instead): the data path has no collective -- the
+            # ranks only meet at the timing barriers and for the final gather of 8 bytes per cell --, so the weak-scaling line is still
+            # measured, with those meetings going through files on this node; the line says so in config.collective
+            sys.stderr.write(f"bench.py rank {rank}: the RCCL communicator could not be created on every rank ({comm_error}); "
+                             "barriers and the final gather go through files (GPRX_BENCH_TORCH=1 selects the torch.distributed launch path)\n")
+            if os.environ.get("GPRX_BENCH_NO_FILE_EXCHANGE") == "1":
+                sys.exit(3)
+            from gpras_amd.comm import FileExchange
+
+            fx = FileExchange(prefix, rank, world)
+            launcher = "torch-free ranks: environment + file rendezvous; RCCL unavailable, so barriers, max and the gather through files"
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
     # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
@@ -216,6 +226,8 @@ def main():
         check(lib.gprx_synchronize(h), h)
         if comm is not None:
             comm.barrier()
+        elif fx is not None:
+            fx.barrier()
         elif distributed:
             torch.cuda.synchronize()
             dist.barrier()
@@ -243,6 +255,8 @@ def main():
             check(lib.gprx_memcpy_h2d(device, d_mine.ptr, ptr(losses), losses.nbytes))
             comm.all_gather_dev(d_mine, d_all, cells)
             comm.synchronize()
+        elif fx is not None:
+            fx_parts = fx.all_gather(losses)
         else:
             mine = torch.tensor(losses, dtype=torch.float64, device=f"cuda:{local_rank}")
             gathered = [torch.empty_like(mine) for _ in range(world)]
@@ -250,10 +264,12 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
-        all_losses = d_all.to_array((world, cells)) if comm is not None else torch.stack(gathered).cpu().numpy()
+        all_losses = d_all.to_array((world, cells)) if comm is not None else np.stack(fx_parts) if fx is not None else torch.stack(gathered).cpu().numpy()
         assert np.array_equal(all_losses[rank], losses) and np.all(np.isfinite(all_losses))
         if comm is not None:
             elapsed = comm.max(elapsed)  # the slowest rank's time
+        elif fx is not None:
+            elapsed = fx.max(elapsed)
         else:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -281,8 +297,9 @@ def main():
             "cells_per_gpu_per_step": cells,
             "parallelism": f"{cells} independent cells per batched launch sequence per GPU x {world} GPU, one RCCL all_gather at the end",
             "collective": ("none (one process)" if not distributed else "gprx_comm_all_gather (RCCL behind the C ABI, device-resident buffers)" if comm is not None
+                           else f"FILE EXCHANGE on this node, not RCCL (the communicator could not be created: {comm_error})" if fx is not None
                            else f"torch.distributed all_gather (fallback: {comm_error})"),
-            "launcher": launcher if (comm is not None or not distributed) else f"{launcher}; gather through torch.distributed ({comm_error})",
+            "launcher": launcher if (comm is not None or fx is not None or not distributed) else f"{launcher}; gather through torch.distributed ({comm_error})",
             "hip_and_rccl_libraries_mapped": mapped_runtimes(),
         },
     }
@@ -757,6 +774,9 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+    if fx is not None:
+        fx.timeout_s = 3600.0  # (rank 0 may still be in its extras)
+        fx.close()
     if use_torch:
         dist.barrier()
         dist.destroy_process_group()

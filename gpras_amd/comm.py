@@ -104,6 +104,74 @@ def agree(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: f
     return verdict
 
 
+class FileExchange:
+    """Barrier / gather / maximum of a few bytes per rank through files on a path every rank of ONE node sees -- the last resort
+    of ``bench.py`` when the RCCL communicator cannot be created on every rank (its data path has no collective: the ranks only
+    meet at the timing barriers and for the final gather of a few kilobytes).  Never used while ``gprx_comm_*`` works; the bench line
+    says which one ran.  Round n of a rank writes ``<prefix>.fx.<n>.<rank>`` (temporary name + rename) and reads every rank's file
+    of that round; a rank's file of round n - 2 is removed when it enters round n (every reader has passed it by then)."""
+
+    def __init__(self, prefix: str, rank: int, world: int, timeout_s: float = 600.0):
+        self.prefix, self.rank, self.world, self.timeout_s = f"{prefix}.fx", int(rank), int(world), float(timeout_s)
+        self.round = 0
+
+    def _exchange(self, payload: bytes) -> list:
+        self.round += 1
+        base = f"{self.prefix}.{self.round}."
+        tmp = f"{base}{self.rank}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, f"{base}{self.rank}")
+        if self.round > 2:
+            try:
+                os.remove(f"{self.prefix}.{self.round - 2}.{self.rank}")
+            except OSError:
+                pass
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            path = f"{base}{r}"
+            while not os.path.exists(path):
+                if time.time() - t0 > self.timeout_s:
+                    raise TimeoutError(f"rank {self.rank}: rank {r} did not reach exchange {self.round} within {self.timeout_s:.0f} s")
+                time.sleep(0.0005)
+            with open(path, "rb") as f:
+                out.append(f.read())
+        return out
+
+    def barrier(self) -> None:
+        self._exchange(b"")
+
+    def all_gather(self, arr) -> list:
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        return [np.frombuffer(b, dtype=np.float64).reshape(a.shape).copy() for b in self._exchange(a.tobytes())]
+
+    def max(self, value: float) -> float:
+        return float(max(np.frombuffer(b, dtype=np.float64)[0] for b in self._exchange(np.float64(value).tobytes())))
+
+    def close(self) -> None:
+        """Last meeting: after it every rank says it has read the final round (``<prefix>.done.<rank>``); rank 0 waits for all of
+        those and removes what is left -- no rank deletes a file another rank may still have to read."""
+
+        def rm(path: str) -> None:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+        self.barrier()
+        rm(f"{self.prefix}.{self.round - 1}.{self.rank}")
+        with open(f"{self.prefix}.done.{self.rank}", "wb"):
+            pass
+        if self.rank == 0:
+            t0 = time.time()
+            for r in range(self.world):
+                while not os.path.exists(f"{self.prefix}.done.{r}") and time.time() - t0 <= self.timeout_s:
+                    time.sleep(0.001)
+            for r in range(self.world):
+                rm(f"{self.prefix}.{self.round}.{r}")
+                rm(f"{self.prefix}.done.{r}")
+
+
 def default_id_prefix() -> str:
     """A rendezvous prefix every rank of ONE launch computes identically and no other launch shares: explicit ``GPRX_ID_FILE``, else
     /tmp + the launcher's port + its run id + the launcher's pid (the ranks are siblings: children of one ``torch.distributed.run``

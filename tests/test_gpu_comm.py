@@ -149,3 +149,17 @@ def test_bench_line_of_a_launched_world_of_one():
     assert out["n_gpus"] == 1 and out["value"] > 0 and "roofline" in out
     assert "gprx_comm_all_gather" in out["config"]["collective"] and out["config"]["launcher"].startswith("torch-free")
     assert len([p for p in out["config"]["hip_and_rccl_libraries_mapped"] if "libamdhip64" in p]) == 1
+
+
+def test_bench_line_when_the_communicator_cannot_be_created():
+    """The last resort of bench.py as a launched rank: no RCCL communicator (forced here) -> barriers, maximum and the final gather
+    through files, the line says so, and the measurement itself is the same batched step."""
+    import json
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", GPRX_BENCH_FORCE_COMM_FAILURE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cells", "8", "--no-extras",
+                          "--batched-only"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["collective"].startswith("FILE EXCHANGE")
+    assert "could not be created" in res.stderr

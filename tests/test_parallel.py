@@ -126,3 +126,36 @@ def test_agree_is_unanimous(tmp_path):
         for p in procs:
             p.join(timeout=30)
         assert got == [(r, want) for r in range(len(votes))]
+
+
+def _fx_worker(prefix, rank, world, q):
+    from gpras_amd.comm import FileExchange
+
+    fx = FileExchange(prefix, rank, world, timeout_s=60.0)
+    fx.barrier()
+    parts = fx.all_gather(np.arange(5.0) + 10.0 * rank)
+    top = fx.max(1.5 * rank)
+    for _ in range(4):  # (old rounds are removed while later ones run)
+        fx.barrier()
+    fx.close()
+    q.put((rank, [p.tolist() for p in parts], top))
+
+
+def test_file_exchange_barrier_gather_and_max_across_three_processes(tmp_path):
+    """bench.py's last resort when the RCCL communicator cannot be created: the ranks' timing barriers, the final gather and the
+    maximum over ranks through files of one node."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    prefix = str(tmp_path / "fx")
+    procs = [ctx.Process(target=_fx_worker, args=(prefix, r, 3, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, parts, top in got:
+        assert parts == [(np.arange(5.0) + 10.0 * r).tolist() for r in range(3)] and top == 3.0
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("fx.fx.")]  # nothing is left behind
