@@ -165,7 +165,7 @@ def main():
     lib = _lib.load()
     device = local_rank if distributed else 0
     if distributed:
-        from gpras_amd.comm import Communicator, agree, default_id_prefix
+        from gpras_amd.comm import Communicator, default_id_prefix, report
 
         prefix = default_id_prefix()
         try:
@@ -183,10 +183,15 @@ def main():
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm, comm_error = None, comm_error or "another rank could not create its communicator"
-        elif world > 1 and not agree(prefix, "comm", rank, world, comm is not None):
-            if comm is not None:
-                comm.close()
-            comm, comm_error = None, comm_error or "another rank could not create its communicator"
+        elif world > 1:
+            said = report(prefix, "comm", rank, world, comm is not None)
+            if None in said:  # a rank that is not there cannot take part in any exchange: end the run
+                sys.stderr.write(f"bench.py rank {rank}: rank(s) {[r for r, v in enumerate(said) if v is None]} did not report -- giving up\n")
+                sys.exit(3)
+            if not all(said):
+                if comm is not None:
+                    comm.close()
+                comm, comm_error = None, comm_error or "another rank could not create its communicator"
         if comm is None and not use_torch:
             # last resort (GPRX_BENCH_NO_FILE_EXCHANGE=1: give up with exit code 3 instead): the data path has no collective -- the
             # ranks only meet at the timing barriers and for the final gather of 8 bytes per cell --, so the weak-scaling line is still

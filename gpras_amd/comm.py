@@ -85,23 +85,30 @@ def file_rendezvous(prefix: str, rank: int, world: int, status: str, make_id, ti
     return wait_for(f"{prefix}.id", "the RCCL id of rank 0")
 
 
-def agree(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0) -> bool:
-    """Every rank reports ``ok`` for ``stage`` through files; True only if all ranks said yes (a rank that never reports counts as
-    no after ``timeout_s``).  Used where ranks must take the SAME branch without a working collective (fallback decisions)."""
+def report(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0) -> list:
+    """Every rank reports ``ok`` for ``stage`` through files; returns what each rank said: True, False, or None for a rank that
+    did not report within ``timeout_s`` (dead, or never started)."""
     path = f"{prefix}.{stage}."
     tmp = f"{path}{rank}.tmp{os.getpid()}"
     with open(tmp, "wb") as f:
         f.write(b"1" if ok else b"0")
     os.replace(tmp, f"{path}{rank}")
-    t0, verdict = time.time(), True
+    t0, said = time.time(), []
     for r in range(world):
-        while not os.path.exists(f"{path}{r}"):
-            if time.time() - t0 > timeout_s:
-                return False
+        while not os.path.exists(f"{path}{r}") and time.time() - t0 <= timeout_s:
             time.sleep(0.02)
-        with open(f"{path}{r}", "rb") as f:
-            verdict = verdict and f.read() == b"1"
-    return verdict
+        try:
+            with open(f"{path}{r}", "rb") as f:
+                said.append(f.read() == b"1")
+        except OSError:
+            said.append(None)
+    return said
+
+
+def agree(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0) -> bool:
+    """True only if all ranks said yes for ``stage`` (a rank that never reports counts as no after ``timeout_s``).  Used where ranks
+    must take the SAME branch without a working collective (fallback decisions)."""
+    return all(v is True for v in report(prefix, stage, rank, world, ok, timeout_s))
 
 
 class FileExchange:
