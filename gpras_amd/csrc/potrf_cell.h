@@ -18,6 +18,15 @@
 
 namespace gprx {
 
+// Row tiles per fused pass (they share the B operand; 32 accumulator registers each).  Measured (tools/cell_ni_sweep.sh, 512 cells):
+// 4 tiles 70.7 k fits/s at N = 1024 / 290 k at N = 512 (the kernel sits at the 256-register cap and spills 372 B per lane), 3 tiles
+// 72.2 k / 305 k, 2 tiles 71.5 k / 306 k (228 B of scratch, all in cell_diag), 6 tiles 55 k / 232 k.  A second operand set in flight
+// (two loads ahead) on top of 2 or 3 tiles: no gain (70.7 k / 302 k) -- the kernel is not waiting for its loads.
+#ifndef GPRX_CELL_NI
+#define GPRX_CELL_NI 2
+#endif
+constexpr int CELL_NI = GPRX_CELL_NI;
+
 struct CellArgs {
   double* A;         // cell 0; cells are `cs` doubles apart
   int64_t lda;
@@ -99,9 +108,9 @@ __device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int n
   const int swz = kc_swz(r);
   const int nsteps = j * ni;
   const double* Brow = p.A + (int64_t)j * NB * p.lda;
-  d4 acc[DAG_NI][2][2];
+  d4 acc[CELL_NI][2][2];
 #pragma unroll
-  for (int t = 0; t < DAG_NI; ++t)
+  for (int t = 0; t < CELL_NI; ++t)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -154,7 +163,7 @@ __device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int n
       request_c(0);  // under the last step's MFMAs
     }
 #pragma unroll
-    for (int tt = 0; tt < DAG_NI; ++tt)
+    for (int tt = 0; tt < CELL_NI; ++tt)
       if (tt == t) dag_mma64(acc[tt], sA, sB, wm, wn, g, r, swz);
   }
   if (nsteps == 0) request_c(0);
@@ -162,7 +171,7 @@ __device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int n
   lds_barrier();  // every wave has finished reading the last step's images
   publish(false, true);  // the inverse becomes the B image
 #pragma unroll
-  for (int t = 0; t < DAG_NI; ++t) {
+  for (int t = 0; t < CELL_NI; ++t) {
     if (t < ni) {
       // the updated tile (C + (-1) * sum, one rounding, as gemm_f64) -> A stage image
 #pragma unroll
@@ -277,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void potrf_cell_kernel_t(CellArgs p) {
     const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
     if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
     __syncthreads();
-    for (int i0 = j + 1; i0 < p.R; i0 += DAG_NI) {
-      const int ni = p.R - i0 < DAG_NI ? p.R - i0 : DAG_NI;
+    for (int i0 = j + 1; i0 < p.R; i0 += CELL_NI) {
+      const int ni = p.R - i0 < CELL_NI ? p.R - i0 : CELL_NI;
       cell_panel_fused(tc, i0, ni, j, smem);
       __syncthreads();
     }
