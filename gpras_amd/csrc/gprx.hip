@@ -291,14 +291,19 @@ int ensure_lookahead(gprx_handle h) {
 // per column, each costing two or more ~2 us memory hops, as much as the 1.7 us of MFMA work in a 64^3 tile).
 bool use_dag(const PotrfTuning& tune, int np) { return tune.dag > 0 && np >= NB; }
 
-// Batched cells: the one-workgroup-per-cell factorisation (potrf_cell.h) for matrices of at most 512 rows once the batch has a
-// workgroup for every CU ("cell_kernel": 1 always, -1 never).  Measured on MI355X (tools/cell_probe.py): N = 200 x 300 cells
+// Batched cells: the one-workgroup-per-cell factorisation (potrf_cell.h) for matrices of at most 1024 rows once the batch has
+// enough cells ("cell_kernel": 1 always, -1 never).  Measured on MI355X (tools/cell_probe.py): N = 200 x 300 cells
 // +11 %, N = 512 x 512 cells +15 % over the batched launch sequence, N = 1024 x 512 cells +1.6 % (both stream every operand from
 // HBM there: 512 cells x 8 MB), so larger matrices or fewer cells keep the launch sequence (bit-identical to single calls).
 bool use_cell_kernel(const PotrfTuning& tune, int np, int cells) {
   if (tune.cell_kernel < 0) return false;
   if (tune.cell_kernel > 0) return true;
-  return (np <= 512 && cells >= 256) || (np <= 1024 && cells >= 512);  // (N = 1024: +4.5 % since the kernel solves in its update pass)
+  // measured crossovers (tools/batch_n1024.py, fits/s cell kernel vs launch sequence): N = 256: 137 k vs 118 k at 32 cells (76 k vs 92 k
+  // at 16); N = 512: tie at 128 cells, 262 k vs 223 k at 256; N = 1024: 64.3 k vs 62.5 k at 256 cells, 71 k vs 67.8 k at 512, 38 k vs
+  // 53 k at 128 -- one workgroup per cell needs a cell for every CU before it beats launches that spread one cell over many
+  if (np <= 256) return cells >= 32;
+  if (np <= 512) return cells >= 160;
+  return np <= 1024 && cells >= 256;
 }
 
 // with_alpha = false: the backward substitution is left out -- the caller goes on to the gradient, which forms alpha from the

@@ -124,7 +124,10 @@ int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const
  * is launched once for all cells (cell index in the grid), so small matrices still fill the GPU.  thetas: (count,
  * n_theta); losses (may be NULL): count training losses, NaN for a cell whose matrix is not positive definite; status
  * (may be NULL): per-cell GPRX_OK / GPRX_ENOTPD.  Returns GPRX_ENOTPD if any cell failed (the others are valid).
- * Results are bit-identical to gprx_factorize on each cell.  The factorisations stay resident in slots 0..count-1
+ * Results are bit-identical to gprx_factorize on each cell -- except where many SMALL matrices take the one-workgroup-per-cell
+ * factorisation (default: N <= 256 from 32 cells, N <= 512 from 160, N <= 1024 from 256; tuning key "cell_kernel" = -1 forbids it,
+ * 1 forces it): the same tile products with a tile's whole update formed as one sum, equal to the launch sequence to rounding
+ * (1e-13 relative on the loss, tests/test_gpu_cells.py).  The factorisations stay resident in slots 0..count-1
  * until the next batch; gprx_select_slot makes one of them current for gprx_predict / gprx_predict_dev. */
 int gprx_factorize_batch(gprx_handle h, int count, const int* units, const double* thetas, int mask, double* losses, int* status);
 int gprx_select_slot(gprx_handle h, int slot);
@@ -345,6 +348,8 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * (1: single stream), "panel_rows" (128 | 256 rows per panel workgroup), "panel_occ" (2 | 3 workgroups per CU),
  * "inblock" (1: right-looking K = 64 strips inside an outer block instead of recursive halving), "split_panel"
  * (1: always one diagonal workgroup + a rows-only kernel per panel, -1: never; default: from 24 cells per launch on).
+ * "cell_kernel" (1: batched cells always take the one-workgroup-per-cell factorisation, -1: never; default by size, see
+ * gprx_factorize_batch).
  * "split_updates" (1: ONE matrix's in-block and HEAD updates with K >= 256 are split by columns -- the 64 columns the next panel
  * needs on the main stream, the rest in dyadic pieces on a side stream behind events; bit-identical factor, measured slower).
  * "dag" (1: ONE matrix is factored by the tile-DAG kernel -- a single persistent launch, the dependent chain of diagonal
