@@ -292,9 +292,8 @@ int ensure_lookahead(gprx_handle h) {
 bool use_dag(const PotrfTuning& tune, int np) { return tune.dag > 0 && np >= NB; }
 
 // Batched cells: the one-workgroup-per-cell factorisation (potrf_cell.h) for matrices of at most 1024 rows once the batch has
-// enough cells ("cell_kernel": 1 always, -1 never).  Measured on MI355X (tools/cell_probe.py): N = 200 x 300 cells
-// +11 %, N = 512 x 512 cells +15 % over the batched launch sequence, N = 1024 x 512 cells +1.6 % (both stream every operand from
-// HBM there: 512 cells x 8 MB), so larger matrices or fewer cells keep the launch sequence (bit-identical to single calls).
+// enough cells ("cell_kernel": 1 always, -1 never).  Equal to the batched launch sequence to rounding, not bit for bit (a tile's
+// whole update is one sum there); larger matrices or fewer cells keep the launch sequence (bit-identical to single calls).
 bool use_cell_kernel(const PotrfTuning& tune, int np, int cells) {
   if (tune.cell_kernel < 0) return false;
   if (tune.cell_kernel > 0) return true;

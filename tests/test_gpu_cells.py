@@ -1,5 +1,5 @@
 """The one-workgroup-per-cell Cholesky for many small matrices (gpras_amd/csrc/potrf_cell.h; "cell_kernel" = 1 forces it, -1
-forbids it, default: N <= 512 with >= 256 cells, N <= 1024 with >= 512 cells) through gprx_factorize_batch /
+forbids it, default: N <= 256 from 32 cells, N <= 512 from 160, N <= 1024 from 256) through gprx_factorize_batch /
 gprx_objective_batch: against the batched launch sequence (same tile products, another summation grouping: equal to rounding),
 against the oracle, with a failing cell, and the two-pass form of the kernel bit for bit."""
 
