@@ -500,7 +500,7 @@ def main():
             sizes["N1024_d8_batched_fits_per_s"] = 10 * c1 / (time.perf_counter() - t1)
             sizes["N1024_d8_cells_per_launch"] = c1
             sizes["N1024_d8_batched_tflops"] = sizes["N1024_d8_batched_fits_per_s"] * 1024**3 / 3 / 1e12
-            sizes["N1024_d8_batched_path"] = "one workgroup per cell (potrf_cell.h: the default from 512 cells of N <= 1024); the launch sequence beside it below"
+            sizes["N1024_d8_batched_path"] = "one workgroup per cell (potrf_cell.h: the default from 256 cells of N <= 1024); the launch sequence beside it below"
             check(lib.gprx_set_handle_tuning(h1, b"cell_kernel", -1), h1)
             for _ in range(2):
                 check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
@@ -557,7 +557,7 @@ def main():
                 h5, lambda: check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5),
                 "gemm_f64_kernel<0,1,64,64,0,0,1>: bulk HEAD / TAIL updates with K = 512 and the in-block updates with K >= 256 of ONE matrix")
             lib.gprx_destroy(h5)
-            # small matrices in many cells: one workgroup per cell (potrf_cell.h, the default from 256 cells of N <= 512 and from 512 cells of N <= 1024)
+            # small matrices in many cells: one workgroup per cell (potrf_cell.h; defaults by size: gprx.hip use_cell_kernel)
             c6 = 512
             x6, y6, _ = make_regression(512, DIM, n_outputs=c6, n_test=0, config=2, unit=600)
             units6 = np.arange(c6, dtype=np.int32)
