@@ -202,7 +202,7 @@ def main():
                 sys.exit(3)
             from gpras_amd.comm import FileExchange
 
-            fx = FileExchange(prefix, rank, world)
+            fx = FileExchange(prefix, rank, world, timeout_s=180.0)  # (a rank that dies later ends the others after 3 minutes)
             launcher = "torch-free ranks: environment + file rendezvous; RCCL unavailable, so barriers, max and the gather through files"
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
