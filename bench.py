@@ -69,13 +69,23 @@ def parse_args():
     ap.add_argument("--cells", type=int, default=CELLS_PER_STEP, help="independent cells per GPU per step")
     ap.add_argument("--no-extras", action="store_true", help="skip F2/F3/predict/cpu legs (profiling runs)")
     ap.add_argument("--batched-only", action="store_true", help="profiling runs: no single-cell calls either, so every launch in a trace belongs to a batched step")
+    ap.add_argument("--only-c4", action="store_true", help="of the secondary legs run only configs[3] (C4: every rank predicts its share, one gather to rank 0)")
+    ap.add_argument("--c4-cells", type=int, default=1250, help="cells per rank in the C4 leg (configs[3]: 10 000 cells over 8 GPUs)")
+    ap.add_argument("--c4-points", type=int, default=N_TEST, help="test points per cell in the C4 leg")
     return ap.parse_args()
+
+
+def worst_code(codes):
+    """Exit code of a launch from its ranks' ``Popen.wait()`` values: a rank killed by signal S reports -S and counts as 128 + S
+    (max([0, -6]) == 0 hid exactly the aborts this project needs to see)."""
+    return max((128 - c) if c < 0 else c for c in codes)
 
 
 def spawn_ranks(args):
     """``python bench.py --gpus N`` without a launcher: this process -- which has made NO GPU call -- starts N fresh rank
     processes (RANK / LOCAL_RANK / WORLD_SIZE and a private rendezvous prefix in the environment), waits for them and exits
-    with the worst of their codes.  Rank 0 inherits stdout (the JSON line).  No torch in any of them."""
+    with the worst of their codes -- a rank killed by a signal (Popen reports -SIGNUM: -6 / -11 after a GPU fault) counts as 128 + SIGNUM,
+    never as "less than 0 = fine"; every rank's code goes to stderr.  Rank 0 inherits stdout (the JSON line).  No torch in any of them."""
     import shutil
     import subprocess
     import tempfile
@@ -87,14 +97,25 @@ def spawn_ranks(args):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), GPRX_ID_FILE=os.path.join(tmp, "rccl"),
                        HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-        codes = []
-        for pr in procs:
-            try:
-                codes.append(pr.wait(timeout=3000))
-            except subprocess.TimeoutExpired:
-                pr.kill()  # (exactly the process started above)
-                codes.append(124)
-        return max(codes)
+        # wait for all of them; once one rank has ended badly the others get a minute to notice (they may be blocked in a collective
+        # that rank will never join -- RCCL has no timeout) and are then ended, so that the launch always returns
+        _time = time
+        t_start, first_bad = _time.time(), None
+        while any(pr.poll() is None for pr in procs):
+            if first_bad is None and any(pr.poll() not in (None, 0) for pr in procs):
+                first_bad = _time.time()
+            if (first_bad is not None and _time.time() - first_bad > 60.0) or _time.time() - t_start > 3000.0:
+                for pr in procs:
+                    if pr.poll() is None:
+                        pr.kill()  # (exactly the processes started above)
+                break
+            _time.sleep(0.2)
+        codes = [pr.wait() for pr in procs]
+        worst = worst_code(codes)
+        if worst:
+            for r, c in enumerate(codes):
+                sys.stderr.write(f"bench.py: rank {r} ended with " + (f"signal {-c}" if c < 0 else f"exit code {c}") + "\n")
+        return worst
     finally:
         for pr in procs:
             if pr.poll() is None:
@@ -193,24 +214,26 @@ def main():
                     comm.close()
                 comm, comm_error = None, comm_error or "another rank could not create its communicator"
         if comm is None and not use_torch:
-            # last resort (GPRX_BENCH_NO_FILE_EXCHANGE=1: give up with exit code 3 instead): the data path has no collective -- the
-            # ranks only meet at the timing barriers and for the final gather of 8 bytes per cell --, so the weak-scaling line is still
-            # measured, with those meetings going through files on this node; the line says so in config.collective
-            sys.stderr.write(f"bench.py rank {rank}: the RCCL communicator could not be created on every rank ({comm_error}); "
-                             "barriers and the final gather go through files (GPRX_BENCH_TORCH=1 selects the torch.distributed launch path)\n")
-            if os.environ.get("GPRX_BENCH_NO_FILE_EXCHANGE") == "1":
+            # No communicator on every rank.  The line this run is for measures the path WITH its RCCL gather (north_star), so the default is
+            # to end here, loudly: exit code 3 and every reason on stderr.  GPRX_BENCH_FILE_EXCHANGE=1 opts in to the shard-scaling
+            # measurement without RCCL: the data path has no collective -- the ranks only meet at the timing barriers and for the final
+            # gather of 8 bytes per cell -- and those meetings then go through files on this node; config.collective says so.
+            sys.stderr.write(f"bench.py rank {rank}: the RCCL communicator could not be created on every rank ({comm_error})\n")
+            if os.environ.get("GPRX_BENCH_FILE_EXCHANGE") != "1":
+                sys.stderr.write(f"bench.py rank {rank}: giving up (exit 3).  GPRX_BENCH_FILE_EXCHANGE=1 measures the shards with barriers and the gather "
+                                 "through files instead; GPRX_BENCH_TORCH=1 selects the torch.distributed launch path\n")
                 sys.exit(3)
             from gpras_amd.comm import FileExchange
 
             fx = FileExchange(prefix, rank, world, timeout_s=180.0)  # (a rank that dies later ends the others after 3 minutes)
-            launcher = "torch-free ranks: environment + file rendezvous; RCCL unavailable, so barriers, max and the gather through files"
+            launcher = "torch-free ranks: environment + file rendezvous; RCCL unavailable, so barriers, max and the gather through files (opt-in)"
 
     # ---- workload: `cells` independent cells per rank, seeds 1000 * config + unit ----
     # One handle per rank: x (N, d) and one y column per cell, resident in HBM before the timed region.
     from gpras_amd.model import NOISE_LOWER, softplus_inv
 
     cells = max(1, args.cells)
-    x, y, xs = make_regression(N_TRAIN, DIM, n_outputs=cells, n_test=N_TEST if rank == 0 else 0, config=2, unit=rank)
+    x, y, xs = make_regression(N_TRAIN, DIM, n_outputs=cells, n_test=N_TEST, config=2, unit=rank)
     h = C.c_void_p()
     check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h)))
     check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
@@ -280,6 +303,12 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
     fits_per_s = world * cells * args.steps / elapsed
+    # "did RCCL see N ranks" from the record itself: ncclCommCount of the communicator, and the distinct rank numbers that came back
+    # through an RCCL all-gather of every rank's ncclCommUserRank
+    rccl_ranks_seen = None
+    if comm is not None:
+        r_seen, w_seen = comm.rank_and_world_seen_by_rccl()
+        rccl_ranks_seen = {"ncclCommCount": w_seen, "distinct_ranks_gathered": len({int(v[0]) for v in comm.all_gather(np.array([float(r_seen)]))})}
 
     result = {
         "metric": "gp_fits_per_sec",
@@ -305,9 +334,96 @@ def main():
                            else f"FILE EXCHANGE on this node, not RCCL (the communicator could not be created: {comm_error})" if fx is not None
                            else f"torch.distributed all_gather (fallback: {comm_error})"),
             "launcher": launcher if (comm is not None or fx is not None or not distributed) else f"{launcher}; gather through torch.distributed ({comm_error})",
+            "rccl_ranks_seen": rccl_ranks_seen,
             "hip_and_rccl_libraries_mapped": mapped_runtimes(),
         },
     }
+
+    # ---- BASELINE configs[3] (C4), MEASURED at one GPU's full share: `--c4-cells` (1250 = 10 000 / 8) independent cells, each fitted and
+    # predicted (mean + variance, noise included) at the shared `--c4-points` (100 000) test points through gprx_predict_batch_dev into ONE
+    # device block [means (cells, N*) | variances (cells, N*)] (2.0 GB), in chunks that fit the free HBM next to the factors (L and L^-1 of a
+    # chunk's cells: gprx_cell_bytes); then the ONE collective north_star names: gprx_comm_gather of every rank's block to rank 0 over RCCL
+    # (reference loop: gpr.py:336-341).  Every rank runs it (so that a launch with N ranks measures N shares and the real gather).
+    c4 = None
+    if (not args.no_extras and not args.batched_only) or args.only_c4:
+        try:
+            n_c4, ns4 = max(1, args.c4_cells), max(1, min(args.c4_points, N_TEST))
+            xs4 = np.ascontiguousarray(xs[:ns4])
+            dxs4 = DeviceBuffer.from_array(xs4, device)
+            block_elems = 2 * n_c4 * ns4
+            block = DeviceBuffer(8 * block_elems, device)
+            nb, fr, tot = C.c_int64(), C.c_int64(), C.c_int64()
+            check(lib.gprx_cell_bytes(h, 1, C.byref(nb)), h)
+            check(lib.gprx_mem_info(device, C.byref(fr), C.byref(tot)))
+            # (the arena of `cells` slots exists already: a chunk of at most `cells` cells only adds the L^-1 workspace, which gprx_cell_bytes
+            # over-counts by the arena cell -- safe side)
+            chunk = int(max(1, min(cells, n_c4, (fr.value - 0.1 * tot.value) // max(nb.value, 1))))
+            units4 = np.ascontiguousarray(np.arange(n_c4, dtype=np.int32) % cells)
+            spread4 = np.random.default_rng(3000 + rank).uniform(-0.15, 0.15, size=(n_c4, 3))
+            spread4[0] = 0.0
+            thetas4 = np.ascontiguousarray(theta[None, :] + spread4)
+            check(lib.gprx_predict_batch_dev(h, 1, ptr(units4), ptr(thetas4), None, dxs4.ptr, min(ns4, 1024), block.ptr, block.at(n_c4 * ns4), 1), h)  # (allocations)
+            sync_all()
+            t1 = time.perf_counter()
+            for lo in range(0, n_c4, chunk):
+                cnt = min(chunk, n_c4 - lo)
+                u_part, t_part = units4[lo:lo + cnt], thetas4[lo:lo + cnt]
+                check(lib.gprx_predict_batch_dev(h, cnt, ptr(u_part), ptr(t_part), None, dxs4.ptr, ns4, block.at(lo * ns4), block.at((n_c4 + lo) * ns4), 1), h)
+                if rank == 0:
+                    sys.stderr.write(f"bench.py: C4 leg {lo + cnt} / {n_c4} cells, {time.perf_counter() - t1:.1f} s\n")
+            check(lib.gprx_synchronize(h), h)
+            t_c4 = time.perf_counter() - t1
+            flops4 = n_c4 * (float(N_TRAIN) ** 2 * ns4 + 2.0 * N_TRAIN * ns4 + 2.0 * N_TRAIN ** 3 / 3)  # predict + (Cholesky + L^-1) per cell
+            c4 = {"cells_per_gpu": n_c4, "n_test": ns4, "cells_per_chunk": chunk, "block_GB_per_gpu": 8e-9 * block_elems,
+                  "seconds_this_gpu": t_c4, "cells_per_s_per_gpu": n_c4 / t_c4, "points_per_s_per_gpu": n_c4 * ns4 / t_c4,
+                  "tflops_predict_plus_factor_plus_inverse": flops4 / t_c4 / 1e12}
+            c4["frac_of_fp64_mfma_peak"] = c4["tflops_predict_plus_factor_plus_inverse"] / FP64_MFMA_PEAK_TFLOPS
+            c4_cell0 = (block.to_array((min(ns4, 2000),)), np.empty(min(ns4, 2000)))  # cell 0 (the reference's initial hyperparameters): mean, variance
+            check(lib.gprx_memcpy_d2h(device, ptr(c4_cell0[1]), block.at(n_c4 * ns4), c4_cell0[1].nbytes))
+            if comm is not None:
+                t_all = comm.max(t_c4)  # the slowest rank's share
+                recv = DeviceBuffer(8 * block_elems * world, device) if rank == 0 else None
+                comm.barrier()
+                t1 = time.perf_counter()
+                comm.gather_dev(block, recv, block_elems, 0)
+                comm.synchronize()
+                t_g = time.perf_counter() - t1
+                comm.barrier()
+                c4["seconds_slowest_gpu"] = t_all
+                c4["cells_per_s_all_gpus"] = world * n_c4 / t_all
+                c4["gather_seconds_on_root"] = t_g
+                inbound = 8.0 * block_elems * max(world - 1, 1)
+                c4["C4_gather_GBps"] = inbound / t_g / 1e9
+                c4["gather_note"] = (f"gprx_comm_gather (grouped ncclSend / ncclRecv) of {world} blocks of {8e-9 * block_elems:.2f} GB to rank 0; GB/s = bytes arriving at the root from the "
+                                     f"other {world - 1} rank(s) / time on the root" if world > 1 else
+                                     "world of one: gprx_comm_gather degenerates to the root's own send/receive pair (a device copy), no xGMI traffic")
+                if rank == 0:
+                    ok_rows = True
+                    for r in range(world):  # cell 0 of every rank's block arrived (own block: equal to what was sent)
+                        got = np.empty(min(ns4, 2000))
+                        check(lib.gprx_memcpy_d2h(device, ptr(got), recv.at(r * block_elems), got.nbytes))
+                        ok_rows = ok_rows and bool(np.all(np.isfinite(got))) and (r != 0 or np.array_equal(got, c4_cell0[0]))
+                    c4["gathered_blocks_checked"] = ok_rows
+                    recv.free()
+            else:
+                c4["seconds_slowest_gpu"] = fx.max(t_c4) if fx is not None else t_c4
+                c4["C4_gather_GBps"] = None
+                c4["gather_note"] = "no RCCL communicator in this run: the gather leg was not measured"
+            c4["seconds_for_10k_cells_on_8_gpus"] = (c4["seconds_slowest_gpu"] * (1250.0 / n_c4) * (100000.0 / ns4)) if (n_c4, ns4) != (1250, 100000) else c4["seconds_slowest_gpu"]
+            c4["seconds_for_10k_cells_on_8_gpus_is"] = ("measured: this rank count x 1250 cells x 100 000 points" if (n_c4, ns4) == (1250, 100000) else "SCALED from a reduced --c4-cells / --c4-points run") + ("" if world == 8 else f"; with {world} of the 8 GPUs present, each running one GPU's full share (shards are independent)")
+            block.free()
+            dxs4.free()
+        except Exception as exc:  # noqa: BLE001  (a rank that fails here cannot take part in the gather: the others must not wait for it)
+            import traceback
+
+            traceback.print_exc()
+            if world > 1:
+                sys.stderr.write(f"bench.py rank {rank}: the C4 leg failed ({type(exc).__name__}: {exc}); ending the run so that no rank waits in the gather\n")
+                sys.stderr.flush()
+                os._exit(4)
+            c4 = {"error": f"{type(exc).__name__}: {exc}"}
+        if c4 is not None:
+            result["C4"] = c4
 
     if rank == 0:
         # ---- roofline of the dominant kernel: instrumented pass over the same batched step, HIP events around every launch ----
@@ -375,7 +491,8 @@ def main():
             "frac_of_8TBps": k1_bytes.value / (k1_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms.value > 0 else None,
             "stage_ms_with_parameter_upload": ms[0], "stage_GBps": kmat_bytes / (ms[0] * 1e-3) / 1e9}
 
-    if rank == 0 and not args.no_extras and not args.batched_only:
+    x1 = y1 = x5 = y5 = xs5 = gpu_mean1 = gpu_mean5 = None
+    if rank == 0 and not args.no_extras and not args.batched_only and not args.only_c4:
         # (the secondary measurements must never cost the headline line: a failure is reported, not raised)
         try:
             extra = {}
@@ -399,25 +516,25 @@ def main():
             fit_one()
             dxs = DeviceBuffer.from_array(xs, device)
             dmean, dvar = DeviceBuffer(8 * N_TEST, device), DeviceBuffer(8 * N_TEST, device)
-            check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
-            check(lib.gprx_synchronize(h), h)
-            t1 = time.perf_counter()
-            check(lib.gprx_predict_dev(h, dxs.ptr, N_TEST, dmean.ptr, dvar.ptr, 1), h)
-            check(lib.gprx_synchronize(h), h)
-            tp = time.perf_counter() - t1
-            extra["predict_points_per_s"] = N_TEST / tp
-            extra["predict_tflops"] = (N_TRAIN**2 * N_TEST + 2.0 * N_TRAIN * N_TEST) / tp / 1e12
+            def predict_rate(handle, dx, ntest, dm, dv, n_train):
+                """device-resident predict (mean + variance, noise included) at `ntest` points of the handle's current factorisation: best of 3
+                after a warm call (which also forms L^-1); flops = N^2 N* + 2 N N* """
+                best_t = np.inf
+                for rep in range(4):
+                    t1 = time.perf_counter()
+                    check(lib.gprx_predict_dev(handle, dx.ptr, ntest, dm.ptr, dv.ptr, 1), handle)
+                    check(lib.gprx_synchronize(handle), handle)
+                    if rep:
+                        best_t = min(best_t, time.perf_counter() - t1)
+                tf = (float(n_train) ** 2 * ntest + 2.0 * n_train * ntest) / best_t / 1e12
+                return {"points_per_s": ntest / best_t, "tflops": tf, "frac_of_fp64_mfma_peak": tf / FP64_MFMA_PEAK_TFLOPS, "n_test": ntest, "timing": "best of 3"}
+
+            pr4 = predict_rate(h, dxs, N_TEST, dmean, dvar, N_TRAIN)
+            extra["predict_points_per_s"] = pr4["points_per_s"]
+            extra["predict_tflops"] = pr4["tflops"]
+            extra["predict_frac_of_fp64_mfma_peak"] = pr4["frac_of_fp64_mfma_peak"]
+            extra["predict_timing"] = "best of 3, device-resident"
             extra["predict_n_test"] = N_TEST
-            # BASELINE configs[3] per GPU: independent cells, each fitted (batched) and predicted at the shared 100k test points
-            # (gprx_predict_batch: host buffers in and out, i.e. PCIe-inclusive)
-            c4 = 8
-            pm, pv = np.zeros((c4, N_TEST)), np.zeros((c4, N_TEST))
-            check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), 1000, ptr(pm), ptr(pv), 1), h)  # (allocations)
-            t1 = time.perf_counter()
-            check(lib.gprx_predict_batch(h, c4, ptr(units), ptr(thetas), None, ptr(xs), N_TEST, ptr(pm), ptr(pv), 1), h)
-            tc4 = time.perf_counter() - t1
-            extra["C4_fit_plus_predict_100k_cells_per_s"] = c4 / tc4
-            extra["C4_seconds_for_10k_cells_on_8_gpus_extrapolated"] = 10000 / 8 / (c4 / tc4)
             gpu_mean = dmean.to_array((N_TEST,))[:2000]
             gpu_var = dvar.to_array((N_TEST,))[:2000]
             # F3: BASELINE configs[2] -- Matern-5/2 ARD, 50 L-BFGS-B iterations on the exact LML
@@ -534,9 +651,14 @@ def main():
             for _ in range(10):
                 check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
             sizes["N1024_d8_single_cell_ms"] = 1e2 * (time.perf_counter() - t1)
+            # predictive mean + variance at the other sizes of the target (north_star: N in {1k, 4k, 16k}), same 100 000 points
+            pr1 = predict_rate(h1, dxs, N_TEST, dmean, dvar, 1024)
+            sizes["N1024_d8_predict_points_per_s"] = pr1["points_per_s"]
+            sizes["N1024_d8_predict"] = pr1
+            gpu_mean1, gpu_var1 = dmean.to_array((2000,)), dvar.to_array((2000,))
             lib.gprx_destroy(h1)
             n5, d5 = 16384, 12
-            x5, y5, _ = make_regression(n5, d5, n_outputs=1, n_test=0, config=5, unit=0)
+            x5, y5, xs5 = make_regression(n5, d5, n_outputs=1, n_test=N_TEST, config=5, unit=0)
             h5 = C.c_void_p()
             check(lib.gprx_create(device, n5, d5, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h5)))
             check(lib.gprx_set_data(h5, ptr(x5), ptr(y5), 1), h5)
@@ -556,6 +678,12 @@ def main():
             sizes["N16384_d12_roofline"] = roofline_block(
                 h5, lambda: check(lib.gprx_factorize(h5, 0, ptr(th5), None, mask, C.byref(loss)), h5),
                 "gemm_f64_kernel<0,1,64,64,0,0,1>: bulk HEAD / TAIL updates with K = 512 and the in-block updates with K >= 256 of ONE matrix")
+            dxs5 = DeviceBuffer.from_array(xs5, device)
+            pr5 = predict_rate(h5, dxs5, N_TEST, dmean, dvar, n5)
+            sizes["N16384_d12_predict_points_per_s"] = pr5["points_per_s"]
+            sizes["N16384_d12_predict"] = pr5
+            gpu_mean5, gpu_var5 = dmean.to_array((2000,)), dvar.to_array((2000,))
+            dxs5.free()
             lib.gprx_destroy(h5)
             # small matrices in many cells: one workgroup per cell (potrf_cell.h; defaults by size: gprx.hip use_cell_kernel)
             c6 = 512
@@ -564,9 +692,9 @@ def main():
             thetas6 = np.ascontiguousarray(np.tile(thetas, (c6 // cells + 1, 1))[:c6])
             losses6, status6 = np.zeros(c6), np.zeros(c6, dtype=np.int32)
             for key, knob in (("launch_sequence", -1), ("one_workgroup_per_cell", 1)):
-                check(lib.gprx_set_tuning(b"cell_kernel", knob))
                 h6 = C.c_void_p()
                 check(lib.gprx_create(device, 512, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h6)))
+                check(lib.gprx_set_handle_tuning(h6, b"cell_kernel", knob), h6)  # (this handle only: no process-wide knob to restore)
                 check(lib.gprx_set_data(h6, ptr(x6), ptr(y6), c6), h6)
                 for _ in range(2):
                     check(lib.gprx_factorize_batch(h6, c6, ptr(units6), ptr(thetas6), mask, ptr(losses6), ptr(status6)), h6)
@@ -575,7 +703,6 @@ def main():
                     check(lib.gprx_factorize_batch(h6, c6, ptr(units6), ptr(thetas6), mask, ptr(losses6), ptr(status6)), h6)
                 sizes[f"N512_d8_batched_fits_per_s_{key}"] = 10 * c6 / (time.perf_counter() - t1)
                 lib.gprx_destroy(h6)
-            check(lib.gprx_set_tuning(b"cell_kernel", 0))
             # the opt-in tile-DAG factorisation of a lone matrix (potrf_dag.h), for the record beside single_cell_ms_per_fit
             h7 = C.c_void_p()
             check(lib.gprx_create(device, N_TRAIN, DIM, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h7)))
@@ -756,12 +883,66 @@ def main():
             result["cpu_baseline"] = {
                 "value": 1.0 / best,
                 "unit": "fits/s",
-                "cores": int(best_threads),
+                "cores": int(best_threads),  # = the threads actually used (the BLAS pool); the host has host_cpu_count hardware threads
+                "blas_threads": int(best_threads),
                 "kind": "port",
                 "sample": f"F1 fits at N={N_TRAIN} d={DIM} with oracle/exact.py (numpy + scipy LAPACK, kernel matrix through BLAS), best of 2 at each of {candidates} BLAS threads (best: {best_threads}); predict on 2000 of the {N_TEST} points",
                 "predict_points_per_s": 2000 / tcp,
                 "host_cpu_count": cores,
             }
+
+            # the other two sizes of the target, same oracle, same definitions (fit F1 = kernel build + Cholesky + alpha + LML; predictive mean
+            # + variance at 2000 of the 100 000 points on the factor of that fit); N = 16384 is fitted ONCE (1.5 TFLOP of dpotrf)
+            def limited(nt):
+                return threadpool_limits(limits=nt, user_api="blas") if threadpool_limits else None
+
+            def cpu_sample(xa, ya, ls, xsa, nt, reps):
+                ctx = limited(nt)
+                if ctx is not None:
+                    ctx.__enter__()
+                try:
+                    t_fit = np.inf
+                    for _ in range(reps):
+                        t1 = time.perf_counter()
+                        lfac, alpha = oex.factorize("RBF", xa, ya, 1.0, ls, 1.0, form="expanded")
+                        float(-0.5 * ya @ alpha - np.log(np.diag(lfac)).sum())
+                        t_fit = min(t_fit, time.perf_counter() - t1)
+                    t1 = time.perf_counter()
+                    cm_, cv_ = oex.predict_from_factor("RBF", xa, lfac, alpha, 1.0, ls, 1.0, xsa, form="expanded")
+                    t_pred = time.perf_counter() - t1
+                finally:
+                    if ctx is not None:
+                        ctx.__exit__(None, None, None)
+                return t_fit, t_pred, cm_, cv_
+
+            per_size = {}
+            if x1 is not None and gpu_mean1 is not None:
+                tf1, tp1, cm1, cv1 = cpu_sample(x1, y1[:, 0], l0, xs[:2000], best_threads, 3)
+                per_size["N1024_d8"] = {"fits_per_s": 1.0 / tf1, "predict_points_per_s": 2000 / tp1, "blas_threads": int(best_threads), "sample": "fit best of 3; predict 2000 points once",
+                                        "gpu_predict_mean_rel_err": float(np.max(np.abs(gpu_mean1 - cm1)) / np.max(np.abs(cm1))),
+                                        "gpu_predict_var_rel_err": float(np.max(np.abs(gpu_var1 - cv1) / cv1))}
+            if x5 is not None and gpu_mean5 is not None:
+                # thread count for the large matrix: dpotrf alone on a 8192 x 8192 SPD matrix at a few pool sizes
+                from scipy.linalg import cholesky as _chol
+
+                nt5, tbest = best_threads, np.inf
+                if threadpool_limits:
+                    a8 = np.random.default_rng(5).standard_normal((8192, 64))
+                    a8 = a8 @ a8.T + 8192.0 * np.eye(8192)
+                    for nt in sorted({t for t in (best_threads, 32, 64) if t <= max(blas_threads, 1)}):
+                        with threadpool_limits(limits=nt, user_api="blas"):
+                            t1 = time.perf_counter()
+                            _chol(a8, lower=True)
+                            dt = time.perf_counter() - t1
+                        if dt < tbest:
+                            tbest, nt5 = dt, nt
+                    del a8
+                tf5, tp5, cm5, cv5 = cpu_sample(x5, y5[:, 0], float(np.mean(np.abs(x5))), xs5[:2000], nt5, 1)
+                per_size["N16384_d12"] = {"fits_per_s": 1.0 / tf5, "predict_points_per_s": 2000 / tp5, "blas_threads": int(nt5), "sample": "fit ONCE; predict 2000 points once",
+                                          "gpu_predict_mean_rel_err": float(np.max(np.abs(gpu_mean5 - cm5)) / np.max(np.abs(cm5))),
+                                          "gpu_predict_var_rel_err": float(np.max(np.abs(gpu_var5 - cv5) / cv5))}
+            per_size["N4096_d8"] = {"fits_per_s": 1.0 / best, "predict_points_per_s": 2000 / tcp, "blas_threads": int(best_threads)}
+            result["cpu_baseline"]["per_size"] = per_size
             fit_step()
             result["parity_at_bench_size"] = {
                 "batched_cell0_equals_single_call_bitwise": bool(losses[0] == loss.value),

@@ -38,87 +38,163 @@ def new_unique_id() -> bytes:
     return bytes(buf)
 
 
+_TAGS: dict = {}  # prefix -> the launch tag this process agreed on (file_rendezvous); "" when it never got that far
+
+
+def agreed_tag(prefix: str) -> str:
+    """The per-launch tag ``file_rendezvous`` agreed on for ``prefix`` in this process ("" if it did not get that far).  ``report``
+    and ``FileExchange`` stamp their files with it, so a leftover of another launch under the same prefix is never read as this
+    launch's."""
+    return _TAGS.get(prefix, "")
+
+
+def _publish(path: str, payload: bytes) -> None:
+    """Atomic: temporary name + rename, so a reader never sees half a file.  First line = wall-clock time of the writing."""
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        f.write(repr(time.time()).encode() + b"\n" + payload)
+    os.replace(tmp, path)
+
+
+def _read_fresh(path: str, max_age_s: float):
+    try:
+        with open(path, "rb") as f:
+            stamp, _, payload = f.read().partition(b"\n")
+        return payload if time.time() - float(stamp) <= max_age_s else None
+    except (OSError, ValueError):
+        return None
+
+
+def _rm(path: str) -> None:
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+
+
 def file_rendezvous(prefix: str, rank: int, world: int, status: str, make_id, timeout_s: float = 120.0, max_age_s: float = 900.0) -> bytes:
     """Torch-free rendezvous over files on a path every rank sees (one node: /tmp): returns the id that rank 0 created.
 
-    1. every rank publishes ``status`` ("ok" or an error text) as ``<prefix>.ready.<rank>`` -- written to a temporary name and
-       renamed, so a reader never sees half a file;
-    2. every rank waits for all ``world`` status files: if ANY rank is not "ok", every rank raises the same RuntimeError and
-       nobody enters the collective initialisation (a rank that cannot load RCCL must not leave the others blocked in
-       ncclCommInitRank);
-    3. rank 0 calls ``make_id()`` and publishes ``<prefix>.id``; the others poll for it.
-    Files carry the wall-clock time of their writing and are ignored when older than ``max_age_s`` (leftovers of an earlier
-    launch that reused the prefix)."""
-
-    def publish(path: str, payload: bytes) -> None:
-        tmp = f"{path}.tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(repr(time.time()).encode() + b"\n" + payload)
-        os.replace(tmp, path)
-
-    def read_fresh(path: str):
-        try:
-            with open(path, "rb") as f:
-                stamp, _, payload = f.read().partition(b"\n")
-            return payload if time.time() - float(stamp) <= max_age_s else None
-        except (OSError, ValueError):
-            return None
+    1. every rank publishes ``<prefix>.ready.<rank>``: a stamp of its own (pid + time in ns: no other process ever writes the same)
+       and ``status`` ("ok" or an error text);
+    2. every rank reads all ``world`` ready files, hashes the stamps into a TAG and publishes it as ``<prefix>.ack.<rank>``; it goes
+       on only when every rank's ack carries the same tag, and re-reads the ready files while they do not -- so a leftover ready
+       file of an earlier launch under the same prefix (its rank not started yet, or not there at all) can delay the agreement or
+       make it time out, but never be taken for this launch's: all ranks that leave this step have seen the same, current files;
+    3. if ANY status is not "ok", every rank raises the same RuntimeError and nobody enters the collective initialisation (a rank
+       that cannot load RCCL must not leave the others blocked in ncclCommInitRank);
+    4. rank 0 -- which removed any old ``<prefix>.id`` before step 1 -- calls ``make_id()`` and publishes tag + id; the others
+       accept only an id file that carries the agreed tag.
+    Files carry the wall-clock time of their writing and are ignored when older than ``max_age_s``."""
+    import hashlib
 
     t0 = time.time()
 
-    def wait_for(path: str, what: str) -> bytes:
-        while True:
-            got = read_fresh(path)
-            if got is not None:
-                return got
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"rank {rank}: {what} ({path}) did not appear within {timeout_s:.0f} s")
-            time.sleep(0.02)
+    def expired() -> bool:
+        return time.time() - t0 > timeout_s
 
-    publish(f"{prefix}.ready.{rank}", status.encode())
-    states = [wait_for(f"{prefix}.ready.{r}", f"status of rank {r}").decode() for r in range(world)]
+    if rank == 0:
+        _rm(f"{prefix}.id")
+    _TAGS[prefix] = ""
+    mine = f"{os.getpid()}.{time.time_ns()}"
+    _publish(f"{prefix}.ready.{rank}", mine.encode() + b"\n" + status.encode())
+    tag = states = None
+    published = None
+    while True:
+        got = [_read_fresh(f"{prefix}.ready.{r}", max_age_s) for r in range(world)]
+        missing = [r for r, g in enumerate(got) if g is None]
+        if not missing:
+            pairs = [g.partition(b"\n") for g in got]
+            tag = hashlib.sha1(b"|".join(p[0] for p in pairs)).hexdigest()[:20]
+            states = [p[2].decode() for p in pairs]
+            if tag != published:
+                _publish(f"{prefix}.ack.{rank}", tag.encode())
+                published = tag
+            acks = [_read_fresh(f"{prefix}.ack.{r}", max_age_s) for r in range(world)]
+            if all(a is not None and a.decode() == tag for a in acks):
+                break
+        if expired():
+            what = f"status of rank {missing[0]} ({prefix}.ready.{missing[0]}) did not appear" if missing else "the ranks did not agree on one set of ready files"
+            raise TimeoutError(f"rank {rank}: {what} within {timeout_s:.0f} s")
+        time.sleep(0.02)
+    _TAGS[prefix] = tag
     bad = {r: st for r, st in enumerate(states) if st != "ok"}
     if bad:
         raise RuntimeError(f"the communicator cannot be created on every rank: {bad}")
     if rank == 0:
-        publish(f"{prefix}.id", make_id())
-    return wait_for(f"{prefix}.id", "the RCCL id of rank 0")
+        _publish(f"{prefix}.id", tag.encode() + b"\n" + make_id())
+    while True:
+        got = _read_fresh(f"{prefix}.id", max_age_s)
+        if got is not None:
+            its_tag, _, uid = got.partition(b"\n")
+            if its_tag.decode() == tag:
+                return uid
+        if expired():
+            raise TimeoutError(f"rank {rank}: the RCCL id of rank 0 ({prefix}.id) did not appear within {timeout_s:.0f} s")
+        time.sleep(0.02)
 
 
-def report(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0) -> list:
+def rendezvous_cleanup(prefix: str, rank: int, success: bool) -> None:
+    """Remove this rank's rendezvous files.  After a SUCCESSFUL collective initialisation every rank has read everything: ready, ack
+    and (rank 0) the id go.  After a failure the ready file stays -- another rank may still have to read the status in it, and it is
+    stamped with this launch's pid + time, so no later launch can take it for its own -- while the ack and the id, which nobody may
+    act on any more, go."""
+    _rm(f"{prefix}.ack.{rank}")
+    if rank == 0:
+        _rm(f"{prefix}.id")
+    if success:
+        _rm(f"{prefix}.ready.{rank}")
+
+
+def report(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0, tag: str | None = None) -> list:
     """Every rank reports ``ok`` for ``stage`` through files; returns what each rank said: True, False, or None for a rank that
-    did not report within ``timeout_s`` (dead, or never started)."""
+    did not report within ``timeout_s`` (dead, or never started).  Reports carry the launch tag (``agreed_tag(prefix)`` unless given):
+    a file with another tag -- a leftover, or a rank that never agreed -- counts as not reported."""
+    tag = agreed_tag(prefix) if tag is None else tag
     path = f"{prefix}.{stage}."
     tmp = f"{path}{rank}.tmp{os.getpid()}"
     with open(tmp, "wb") as f:
-        f.write(b"1" if ok else b"0")
+        f.write(tag.encode() + (b":1" if ok else b":0"))
     os.replace(tmp, f"{path}{rank}")
     t0, said = time.time(), []
     for r in range(world):
-        while not os.path.exists(f"{path}{r}") and time.time() - t0 <= timeout_s:
+        val = None
+        while True:
+            try:
+                with open(f"{path}{r}", "rb") as f:
+                    its_tag, _, v = f.read().rpartition(b":")
+                if its_tag.decode() == tag:
+                    val = v == b"1"
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > timeout_s:
+                break
             time.sleep(0.02)
-        try:
-            with open(f"{path}{r}", "rb") as f:
-                said.append(f.read() == b"1")
-        except OSError:
-            said.append(None)
+        said.append(val)
     return said
 
 
-def agree(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0) -> bool:
+def report_cleanup(prefix: str, stage: str, rank: int) -> None:
+    _rm(f"{prefix}.{stage}.{rank}")
+
+
+def agree(prefix: str, stage: str, rank: int, world: int, ok: bool, timeout_s: float = 120.0, tag: str | None = None) -> bool:
     """True only if all ranks said yes for ``stage`` (a rank that never reports counts as no after ``timeout_s``).  Used where ranks
     must take the SAME branch without a working collective (fallback decisions)."""
-    return all(v is True for v in report(prefix, stage, rank, world, ok, timeout_s))
+    return all(v is True for v in report(prefix, stage, rank, world, ok, timeout_s, tag))
 
 
 class FileExchange:
-    """Barrier / gather / maximum of a few bytes per rank through files on a path every rank of ONE node sees -- the last resort
-    of ``bench.py`` when the RCCL communicator cannot be created on every rank (its data path has no collective: the ranks only
-    meet at the timing barriers and for the final gather of a few kilobytes).  Never used while ``gprx_comm_*`` works; the bench line
-    says which one ran.  Round n of a rank writes ``<prefix>.fx.<n>.<rank>`` (temporary name + rename) and reads every rank's file
+    """Barrier / gather / maximum of a few bytes per rank through files on a path every rank of ONE node sees -- an explicit opt-in
+    of ``bench.py`` (GPRX_BENCH_FILE_EXCHANGE=1) for when the RCCL communicator cannot be created on every rank (its data path has no
+    collective: the ranks only meet at the timing barriers and for the final gather of a few kilobytes).  Never used while
+    ``gprx_comm_*`` works; the bench line says which one ran.  Round n of a rank writes ``<prefix>.fx.<n>.<rank>`` (temporary name +
+    rename; first line = the launch tag, and a file with another tag is waited out like a missing one) and reads every rank's file
     of that round; a rank's file of round n - 2 is removed when it enters round n (every reader has passed it by then)."""
 
-    def __init__(self, prefix: str, rank: int, world: int, timeout_s: float = 600.0):
+    def __init__(self, prefix: str, rank: int, world: int, timeout_s: float = 600.0, tag: str | None = None):
+        self.tag = (agreed_tag(prefix) if tag is None else tag).encode()
         self.prefix, self.rank, self.world, self.timeout_s = f"{prefix}.fx", int(rank), int(world), float(timeout_s)
         self.round = 0
 
@@ -127,22 +203,25 @@ class FileExchange:
         base = f"{self.prefix}.{self.round}."
         tmp = f"{base}{self.rank}.tmp{os.getpid()}"
         with open(tmp, "wb") as f:
-            f.write(payload)
+            f.write(self.tag + b"\n" + payload)
         os.replace(tmp, f"{base}{self.rank}")
         if self.round > 2:
-            try:
-                os.remove(f"{self.prefix}.{self.round - 2}.{self.rank}")
-            except OSError:
-                pass
+            _rm(f"{self.prefix}.{self.round - 2}.{self.rank}")
         out, t0 = [], time.time()
         for r in range(self.world):
             path = f"{base}{r}"
-            while not os.path.exists(path):
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        its_tag, _, body = f.read().partition(b"\n")
+                    if its_tag == self.tag:
+                        out.append(body)
+                        break
+                except OSError:
+                    pass
                 if time.time() - t0 > self.timeout_s:
                     raise TimeoutError(f"rank {self.rank}: rank {r} did not reach exchange {self.round} within {self.timeout_s:.0f} s")
                 time.sleep(0.0005)
-            with open(path, "rb") as f:
-                out.append(f.read())
         return out
 
     def barrier(self) -> None:
@@ -158,25 +237,24 @@ class FileExchange:
     def close(self) -> None:
         """Last meeting: after it every rank says it has read the final round (``<prefix>.done.<rank>``); rank 0 waits for all of
         those and removes what is left -- no rank deletes a file another rank may still have to read."""
-
-        def rm(path: str) -> None:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
-
         self.barrier()
-        rm(f"{self.prefix}.{self.round - 1}.{self.rank}")
-        with open(f"{self.prefix}.done.{self.rank}", "wb"):
-            pass
+        _rm(f"{self.prefix}.{self.round - 1}.{self.rank}")
+        with open(f"{self.prefix}.done.{self.rank}", "wb") as f:
+            f.write(self.tag)
         if self.rank == 0:
             t0 = time.time()
             for r in range(self.world):
-                while not os.path.exists(f"{self.prefix}.done.{r}") and time.time() - t0 <= self.timeout_s:
+                while time.time() - t0 <= self.timeout_s:
+                    try:
+                        with open(f"{self.prefix}.done.{r}", "rb") as f:
+                            if f.read() == self.tag:
+                                break
+                    except OSError:
+                        pass
                     time.sleep(0.001)
             for r in range(self.world):
-                rm(f"{self.prefix}.{self.round}.{r}")
-                rm(f"{self.prefix}.done.{r}")
+                _rm(f"{self.prefix}.{self.round}.{r}")
+                _rm(f"{self.prefix}.done.{r}")
 
 
 def default_id_prefix() -> str:
@@ -241,13 +319,13 @@ class Communicator:
         if rc != _lib.GPRX_OK:
             msg = _lib.load().gprx_comm_last_error(None)
             status = f"rank {rank}: {msg.decode() if msg else 'libgprx error ' + str(rc)}"
-        uid = file_rendezvous(id_file, rank, world, status, new_unique_id, timeout_s=timeout_s)
-        comm = cls(device, rank, world, uid)  # (collective: when it returns, every rank has read the id)
-        for leftover in [f"{id_file}.ready.{rank}"] + ([f"{id_file}.id"] if rank == 0 else []):
-            try:
-                os.remove(leftover)
-            except OSError:
-                pass
+        done = False
+        try:
+            uid = file_rendezvous(id_file, rank, world, status, new_unique_id, timeout_s=timeout_s)
+            comm = cls(device, rank, world, uid)  # (collective: when it returns, every rank has read the id)
+            done = True
+        finally:
+            rendezvous_cleanup(id_file, rank, done)
         return comm
 
     # -- lifetime --------------------------------------------------------------------------------------------------
@@ -261,6 +339,12 @@ class Communicator:
             self.close()
         except Exception:
             pass
+
+    def rank_and_world_seen_by_rccl(self) -> tuple:
+        """(rank, world) as RCCL reports them for this communicator (``ncclCommUserRank`` / ``ncclCommCount`` behind ``gprx_comm_rank``)."""
+        r, w = C.c_int(), C.c_int()
+        _check(self._lib.gprx_comm_rank(self._c, C.byref(r), C.byref(w)), self._c)
+        return int(r.value), int(w.value)
 
     # -- collectives (device buffers: gpras_amd._lib.DeviceBuffer or raw device pointers) ---------------------------
     @staticmethod

@@ -30,6 +30,8 @@ struct RcclApi {
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // (optional: what RCCL itself says about the communicator)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   std::string error;
 
   std::mutex mu;
@@ -91,6 +93,8 @@ struct RcclApi {
     Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
     GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
     GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
     if (!error.empty()) {
       lib = nullptr;
       return false;

@@ -390,7 +390,7 @@ std::mutex& capture_mutex() {
 // the device (4 hardware queues, each cell ~1.8x slower under 4-way sharing), the replay mainly frees the host.
 int exact_factorize_replay(gprx_handle h, int unit, const Theta& t) {
   static const bool no_graph = getenv("GPRX_NO_GRAPH") != nullptr;  // escape hatch: eager launches
-  if (h->d > 64 || h->profiling || no_graph || false) return exact_factorize_enqueue(h, unit, t, false);
+  if (h->d > 64 || h->profiling || no_graph) return exact_factorize_enqueue(h, unit, t, false);
   auto it = h->graphs.find(unit);
   if (it == h->graphs.end()) {
     // buffers must exist before capture: a first eager pass allocates them (and is a valid fit by itself)
@@ -418,6 +418,7 @@ int exact_factorize_replay(gprx_handle h, int unit, const Theta& t) {
   h->pin[74] = t.variance;
   h->pin[75] = t.noise;
   HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+  h->dag_used = false;  // a replayed fit is always the launch-per-panel schedule ("dag" applies to eager single factorisations only)
   h->factorized = false;
   h->cur_unit = unit;
   h->variance = t.variance;
@@ -1680,7 +1681,7 @@ int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const
     double lml = 0.0;
     const int rc = exact_factorize_finish(h, &lml);
     if (rc && !first_error) first_error = rc;
-    if (!rc && losses) losses[i] = -(lml + log_prior(h, ts[i], mask));
+    if (losses) losses[i] = rc ? std::numeric_limits<double>::quiet_NaN() : -(lml + log_prior(h, ts[i], mask));
   }
   return first_error;
 }
@@ -2716,6 +2717,10 @@ int gprx_comm_rank(gprx_comm c, int* rank, int* world) {
   if (!c || !rank || !world) return cfail(c, GPRX_EINVAL, "null argument");
   *rank = c->rank;
   *world = c->world;
+  // what RCCL itself reports for this communicator (ncclCommUserRank / ncclCommCount), so that "did RCCL see N ranks" does not rest
+  // on the numbers the caller passed to gprx_comm_init
+  if (rccl().CommUserRank) COMMNCCL(c, rccl().CommUserRank(c->comm, rank));
+  if (rccl().CommCount) COMMNCCL(c, rccl().CommCount(c->comm, world));
   return GPRX_OK;
 }
 

@@ -273,7 +273,7 @@ class GPRAS:
         then assign every saved parameter.  The container is recognised by content; files written by the reference are read
         as far as that is possible without gpflow (``gpras_amd.modelfile.load``)."""
         d = modelfile.load(json_path)
-        inst = cls(d["kernel"], device=device, distance_form=d.get("distance_form", "difference"))
+        inst = cls(d["kernel"], device=device, distance_form=d.get("distance_form"))  # (absent / None: the per-kernel default)
         inst.x = np.asarray(d["data"]["x"], dtype=np.float64)
         inst.y = np.asarray(d["data"]["y"], dtype=np.float64)
         inst._init_models(inst.x, inst.y, d["n_inducing"], "grid", d.get("ard", False))

@@ -20,6 +20,52 @@ from . import _lib
 from ._lib import as_f64, check, ptr
 
 
+def _draws(n: int, n_clusters: int):
+    """The ``RandomState(0)`` draws of ``sklearn.cluster._kmeans._kmeans_plusplus`` as scikit-learn >= 1.3 makes them (they do not
+    depend on the data): the first index by ``choice(n, p=uniform weights)``, then ``uniform(size=n_local_trials)`` per centre."""
+    rs = np.random.RandomState(0)
+    trials = 2 + int(np.log(n_clusters))
+    weight = np.ones(n, dtype=np.float64)
+    first = int(rs.choice(n, p=weight / weight.sum()))
+    uniforms = np.ascontiguousarray(np.stack([rs.uniform(size=trials) for _ in range(n_clusters - 1)]) if n_clusters > 1 else np.zeros((1, trials)))
+    return trials, first, uniforms
+
+
+_DRAWS_MATCH_SKLEARN = None
+
+
+def draws_match_installed_sklearn() -> bool:
+    """Once per process: does the INSTALLED scikit-learn consume its random stream the way ``_draws`` assumes?  A tiny
+    problem (48 well-separated points, 6 centres) is seeded by ``sklearn.cluster.kmeans_plusplus(random_state=0)`` and by a plain
+    numpy replay of its algorithm on ``_draws``; if the picked rows differ -- an older release drew with ``randint`` /
+    ``random_sample``, a future one may change again -- the device seeding is not used and ``kmeans_centers`` asks scikit-learn's own
+    ``kmeans_plusplus`` for the seeds, as it did in round 2 (same result as the reference's call either way, only slower)."""
+    global _DRAWS_MATCH_SKLEARN
+    if _DRAWS_MATCH_SKLEARN is None:
+        try:
+            from sklearn.cluster import kmeans_plusplus
+
+            g = np.random.default_rng(12345)
+            xc = np.ascontiguousarray(g.normal(size=(48, 3)) + 5.0 * g.integers(0, 4, size=(48, 1)))
+            xc -= xc.mean(axis=0)
+            m = 6
+            _, want = kmeans_plusplus(xc, m, random_state=0)
+            trials, first, uniforms = _draws(len(xc), m)
+            d2 = lambda c: ((xc - c) ** 2).sum(axis=1)  # noqa: E731
+            picked, closest = [first], d2(xc[first])
+            for c in range(1, m):
+                cand = np.searchsorted(np.cumsum(closest), uniforms[c - 1] * closest.sum())
+                np.clip(cand, None, len(xc) - 1, out=cand)
+                pots = [np.minimum(closest, d2(xc[i])).sum() for i in cand]
+                best = int(cand[int(np.argmin(pots))])
+                picked.append(best)
+                closest = np.minimum(closest, d2(xc[best]))
+            _DRAWS_MATCH_SKLEARN = bool(np.array_equal(np.asarray(picked), np.asarray(want)))
+        except Exception:  # noqa: BLE001  (no scikit-learn, or an API this code does not know: do not trust the replay)
+            _DRAWS_MATCH_SKLEARN = False
+    return _DRAWS_MATCH_SKLEARN
+
+
 def kmeans_pp_indices(xc, n_clusters: int, device: int = 0):
     """Rows of the (centred) data that ``sklearn.cluster.kmeans_plusplus(xc, n_clusters, random_state=0)`` picks, computed by
     ``gprx_kmeans_pp``.  The draws are made here exactly as ``_kmeans_plusplus`` makes them: ``choice(n, p=uniform)`` for the first
@@ -27,11 +73,7 @@ def kmeans_pp_indices(xc, n_clusters: int, device: int = 0):
     from sklearn.utils.extmath import row_norms
 
     n, _ = xc.shape
-    rs = np.random.RandomState(0)
-    trials = 2 + int(np.log(n_clusters))
-    weight = np.ones(n, dtype=xc.dtype)
-    first = int(rs.choice(n, p=weight / weight.sum()))
-    uniforms = np.ascontiguousarray(np.stack([rs.uniform(size=trials) for _ in range(n_clusters - 1)]) if n_clusters > 1 else np.zeros((1, trials)))
+    trials, first, uniforms = _draws(n, n_clusters)
     xsq = np.ascontiguousarray(row_norms(xc, squared=True), dtype=np.float64)
     indices = np.empty(n_clusters, dtype=np.int64)
     check(_lib.load().gprx_kmeans_pp(device, ptr(xc), n, xc.shape[1], ptr(xsq), int(n_clusters), trials, first, ptr(uniforms), ptr(indices)))
@@ -50,10 +92,10 @@ def kmeans_centers(x, n_clusters: int, device: int = 0, return_info: bool = Fals
     info = {"device": False, "n_iter": None, "labels": None}
     if d <= 64 and 0 < n_clusters <= n:
         trials = 2 + int(np.log(n_clusters))  # _kmeans_plusplus: n_local_trials
-        if trials <= 16:
+        if trials <= 16 and draws_match_installed_sklearn():
             indices = kmeans_pp_indices(xc, n_clusters, device)
             init = xc[indices]
-        else:  # (more than e^14 clusters)
+        else:  # (more than e^14 clusters, or a scikit-learn whose random draws this module does not know)
             init, _ = kmeans_plusplus(xc, n_clusters, x_squared_norms=row_norms(xc, squared=True), random_state=0)
         centers = np.ascontiguousarray(init, dtype=np.float64)
         labels = np.empty(n, dtype=np.int32)

@@ -101,7 +101,7 @@ def _load_npz(path):
         models = []
         for i in range(meta["n_models"]):
             models.append({key: np.array(z["models" + key][i]) for key in PARAM_KEYS if "models" + key in z.files})
-        return {**{k: meta[k] for k in ("format", "kernel", "n_inducing", "ard", "distance_form")}, "data": {"x": z["x"], "y": z["y"]},
+        return {**{k: meta.get(k) for k in ("format", "kernel", "n_inducing", "ard", "distance_form")}, "data": {"x": z["x"], "y": z["y"]},
                 "models": models}
 
 
@@ -240,4 +240,4 @@ def _load_pickle(path):
             out[key] = to_constrained(unconstrained)
         models.append(out)
     return {"format": "reference", "kernel": d["kernel"], "data": d["data"], "n_inducing": d.get("n_inducing"), "ard": False,
-            "distance_form": "difference", "models": models}
+            "distance_form": None, "models": models}  # (None: GPRAS picks gpflow's form where it matters -- the file came from gpflow)

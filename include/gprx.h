@@ -115,7 +115,8 @@ int gprx_factorize(gprx_handle h, int unit, const double* theta, const double* z
 /* Many independent cells on one GPU: factorise `count` exact models (one handle each, all on the caller's
  * thread) by enqueueing every handle's work before waiting for any of them, so the latency-bound panel
  * chains of different cells overlap on the device.  thetas: (count, n_theta); losses: count values.
- * Replaces a Python loop of gprx_factorize calls; each handle is left factorised as by gprx_factorize. */
+ * Replaces a Python loop of gprx_factorize calls; each handle is left factorised as by gprx_factorize.  A cell whose matrix
+ * is not positive definite gets a NaN loss, the others finish, and the call returns the first such error (GPRX_ENOTPD). */
 int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const double* thetas, int mask, double* losses);
 
 /* Batched cells on ONE handle: `count` exact factorisations -- cell i = (units[i], thetas[i]), all on the handle's x,
@@ -204,6 +205,7 @@ int gprx_comm_unique_id(unsigned char* id128);
 int gprx_comm_init(int device, int rank, int world, const unsigned char* id128, gprx_comm* out);
 int gprx_comm_destroy(gprx_comm c);
 const char* gprx_comm_last_error(gprx_comm c);
+/* rank / world as RCCL itself reports them for the communicator (ncclCommUserRank / ncclCommCount), not the caller's numbers */
 int gprx_comm_rank(gprx_comm c, int* rank, int* world);
 int gprx_comm_all_gather(gprx_comm c, const double* send_dev, double* recv_dev, int64_t count);
 int gprx_comm_gather(gprx_comm c, const double* send_dev, double* recv_dev, int64_t count, int root);
@@ -220,7 +222,8 @@ int gprx_memcpy_d2h(int device, void* dst_host, const void* src_dev, int64_t byt
 
 /* ---- building blocks (exported for parity tests, profiling and bench.py) ----------- */
 /* All matrices row-major f64 in device memory, leading dimension in elements.  These run on
- * the NULL stream of `device` and synchronise before returning unless noted. */
+ * the library's non-blocking utility stream of `device` (one per device; the library never touches the legacy NULL stream) and
+ * synchronise that stream before returning unless noted. */
 
 /* out[i, j] = variance * g(r(a_i, b_j)) + (i == j ? diag_add : 0)
  * a: (n1, d), b: (n2, d) device, ls: d host values (lengthscale per dimension; inputs are divided by it).
@@ -355,7 +358,8 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * "dag" (1: ONE matrix is factored by the tile-DAG kernel -- a single persistent launch, the dependent chain of diagonal
  * blocks in one workgroup, every other tile task claimed from a queue and ordered by per-tile version counters in device memory;
  * deterministic, within rounding of the default; default 0 = the launch-per-panel schedule, which measured faster on MI355X:
- * DESIGN.md section 7.2).
+ * DESIGN.md section 3.2b).  Applies to EAGER single factorisations only (gprx_factorize / gprx_objective): the graph replays of
+ * gprx_factorize_many and every batched call always run the launch-per-panel schedule.
  * "poison_workspace" (testing, 1: the L^-1 workspace of the gradient starts as NaN patterns instead of whatever it held -- the
  * gradient never depends on its old contents, and no longer zeroes it).
  * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical.

@@ -103,8 +103,8 @@ def loss(kernel, X, y, w_var, w_len, w_noise, mask=(True, True, True), form="dir
     return -(value + logp)
 
 
-def predict(kernel, X, y, variance, lengthscales, noise, Xs, include_noise=True, form="direct"):
-    L, alpha = factorize(kernel, X, y, variance, lengthscales, noise, form)
+def predict_from_factor(kernel, X, L, alpha, variance, lengthscales, noise, Xs, include_noise=True, form="direct"):
+    """The predictive equations on a factorisation that already exists (``factorize``): what ``predict`` does after its own."""
     Ks = kn.kmat(kernel, X, Xs, variance, lengthscales, form)
     mean = Ks.T @ alpha
     V = solve_triangular(L, Ks, lower=True)
@@ -112,3 +112,8 @@ def predict(kernel, X, y, variance, lengthscales, noise, Xs, include_noise=True,
     if include_noise:
         var = var + noise
     return mean, var
+
+
+def predict(kernel, X, y, variance, lengthscales, noise, Xs, include_noise=True, form="direct"):
+    L, alpha = factorize(kernel, X, y, variance, lengthscales, noise, form)
+    return predict_from_factor(kernel, X, L, alpha, variance, lengthscales, noise, Xs, include_noise, form)

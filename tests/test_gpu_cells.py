@@ -75,26 +75,38 @@ def test_cell_kernel_against_launch_sequence_and_oracle(lib, kernel, n, d, cells
         assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
 
 
-def test_cell_kernel_reports_a_failing_cell_alone(lib):
+NON_PD_VARIANCE = 2.0**40  # with noise 1e-6 the diagonal v + s rounds to v, and sqrt / rsqrt of a power of four are exact: on rows that
+                            # duplicate their predecessor the second pivot is v - (v / sqrt(v))^2 = 0 EXACTLY, on the host and on the device
+
+
+@pytest.mark.parametrize("cell_kernel", [1, -1])
+def test_a_non_positive_definite_cell_is_reported_alone(lib, cell_kernel):
+    """a cell that IS not positive definite in fp64 -- scipy's Cholesky of the oracle's K raises, checked first -- must
+    come back as GPRX_ENOTPD with its own status entry and a NaN loss, from the one-workgroup-per-cell kernel (1) and from the
+    launch sequence (-1), while its neighbours finish with the values they have alone."""
     n, d = 256, 3
     x, y, _ = make_regression(n, d, config=1, unit=1)
     x[1::2] = x[0::2]  # duplicated inputs: singular without the noise term
+    good = np.array([float(v) for v in otr.unconstrain(1.0, 0.9, 0.1)])
+    bad = np.array([NON_PD_VARIANCE, float(otr.unconstrain(1.0, 0.9, 0.1)[1]), -800.0])
+    with pytest.raises(np.linalg.LinAlgError, match="2-th leading minor"):
+        oex.loss("RBF", x, y[:, 0], bad[0], bad[1], bad[2])
     h = handle(lib, n, d, "RBF", x, y, 1)
     try:
-        good = np.concatenate([[otr.unconstrain(1.0, 0.9, 0.1)[0]], [otr.unconstrain(1.0, 0.9, 0.1)[1]], [otr.unconstrain(1.0, 0.9, 0.1)[2]]])
-        bad = good.copy()
-        bad[0], bad[1], bad[-1] = 40.0, 50.0, -800.0
+        check(lib.gprx_set_handle_tuning(h, b"cell_kernel", cell_kernel), h)
         thetas = np.ascontiguousarray(np.stack([good, bad, good, good]))
         units = np.zeros(4, dtype=np.int32)
         losses, status = np.zeros(4), np.zeros(4, dtype=np.int32)
         rc = lib.gprx_factorize_batch(h, 4, ptr(units), ptr(thetas), ALL, ptr(losses), ptr(status))
+        assert rc == _lib.GPRX_ENOTPD
+        assert status[1] == _lib.GPRX_ENOTPD and not status[[0, 2, 3]].any() and np.isnan(losses[1])
         ref = oex.loss("RBF", x, y[:, 0], float(good[0]), float(good[1]), float(good[2]))
         assert abs(losses[0] - ref) <= 1e-9 * abs(ref) and losses[2] == losses[0] and losses[3] == losses[0]
-        if rc == _lib.GPRX_ENOTPD:
-            assert status[1] == _lib.GPRX_ENOTPD and not status[[0, 2, 3]].any() and np.isnan(losses[1])
-            assert lib.gprx_select_slot(h, 1) == _lib.GPRX_ESTATE
-        else:
-            assert rc == _lib.GPRX_OK
+        assert lib.gprx_select_slot(h, 1) == _lib.GPRX_ESTATE  # nothing to predict from
+        assert lib.gprx_select_slot(h, 2) == _lib.GPRX_OK
+        single = C.c_double()  # the lone call names the same pivot as LAPACK (1-based)
+        assert lib.gprx_factorize(h, 0, ptr(bad), None, ALL, C.byref(single)) == _lib.GPRX_ENOTPD
+        assert lib.gprx_last_error(h).endswith(b"pivot 2")
     finally:
         lib.gprx_destroy(h)
 

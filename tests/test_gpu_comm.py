@@ -149,17 +149,43 @@ def test_bench_line_of_a_launched_world_of_one():
     assert out["n_gpus"] == 1 and out["value"] > 0 and "roofline" in out
     assert "gprx_comm_all_gather" in out["config"]["collective"] and out["config"]["launcher"].startswith("torch-free")
     assert len([p for p in out["config"]["hip_and_rccl_libraries_mapped"] if "libamdhip64" in p]) == 1
+    assert out["config"]["rccl_ranks_seen"] == {"ncclCommCount": 1, "distinct_ranks_gathered": 1}
+
+
+def test_bench_c4_leg_of_a_launched_world_of_one():
+    """the C4 leg of bench.py -- every rank predicts its share into ONE device block through gprx_predict_batch_dev in
+    chunks, then ONE gprx_comm_gather of the blocks to rank 0, timed by itself -- as a launched world of one at a reduced size (the same
+    code path the driver's N > 1 launches take; the gather of a world of one is the root's own send / receive pair)."""
+    import json
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cells", "4", "--only-c4",
+                          "--c4-cells", "10", "--c4-points", "3000"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    c4 = out["C4"]
+    assert "error" not in c4, c4
+    assert c4["cells_per_gpu"] == 10 and c4["n_test"] == 3000 and c4["cells_per_chunk"] == 4  # three chunks, the last one ragged
+    assert c4["seconds_this_gpu"] > 0 and c4["C4_gather_GBps"] > 0 and c4["gathered_blocks_checked"] is True
+    assert "SCALED" in c4["seconds_for_10k_cells_on_8_gpus_is"]  # a reduced run never claims to be the measurement
 
 
 def test_bench_line_when_the_communicator_cannot_be_created():
-    """The last resort of bench.py as a launched rank: no RCCL communicator (forced here) -> barriers, maximum and the final gather
-    through files, the line says so, and the measurement itself is the same batched step."""
+    """bench.py as a launched rank without an RCCL communicator (forced here).  Default: NO measurement through files --
+    exit code 3 and the reason on stderr, so that a scaling record can never show shard scaling where the RCCL gather was asked for.
+    With the explicit opt-in GPRX_BENCH_FILE_EXCHANGE=1: barriers, maximum and the final gather through files, and the line says so."""
     import json
 
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", GPRX_BENCH_FORCE_COMM_FAILURE="1")
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cells", "8", "--no-extras",
-                          "--batched-only"], capture_output=True, text=True, timeout=900, env=env)
+    env.pop("GPRX_BENCH_FILE_EXCHANGE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--cells", "8", "--no-extras", "--batched-only"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 3, (res.returncode, res.stderr[-3000:])
+    assert "could not be created" in res.stderr and "forced by GPRX_BENCH_FORCE_COMM_FAILURE" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]  # no JSON line
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, GPRX_BENCH_FILE_EXCHANGE="1"))
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["collective"].startswith("FILE EXCHANGE")
+    assert out["config"]["rccl_ranks_seen"] is None
     assert "could not be created" in res.stderr

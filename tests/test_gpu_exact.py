@@ -119,12 +119,38 @@ def test_factorize_many_matches_single_calls_and_replays(lib):
                 assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
                 check(lib.gprx_factorize(C.c_void_p(handles[c]), int(units[c]), ptr(np.ascontiguousarray(th)), None, ALL, C.byref(single)))
                 assert single.value == losses[c]
-        # a non-positive-definite cell is reported, the others still finish
-        bad = thetas.copy()
-        bad[1, -1] = -800.0  # noise -> 1e-6 on duplicated rows is fine; force failure through a NaN-free but huge lengthscale instead
-        bad[1, 1:-1] = 700.0
-        rc = lib.gprx_factorize_many(cells, handles, ptr(units), ptr(bad), ALL, ptr(losses))
-        assert rc in (_lib.GPRX_OK, _lib.GPRX_ENOTPD)
+    finally:
+        for c in range(cells):
+            lib.gprx_destroy(C.c_void_p(handles[c]))
+
+
+def test_factorize_many_reports_a_non_positive_definite_cell(lib):
+    """one of three cells IS not positive definite in fp64 (rows duplicated, v = 2^40 beside s = 1e-6: the second pivot is
+    exactly zero -- scipy's Cholesky of the oracle's K raises, checked first); gprx_factorize_many must say GPRX_ENOTPD on the eager
+    pass and on the graph replay, give that cell a NaN loss and finish the others."""
+    n, d, cells = 300, 3, 3
+    x, y, _ = make_regression(n, d, n_outputs=1, n_test=0, config=7, unit=9)
+    xdup = x.copy()
+    xdup[1::2] = xdup[0::2]
+    good = np.array([0.3, 0.1, -1.0])
+    bad = np.array([2.0**40, 0.1, -800.0])
+    with pytest.raises(np.linalg.LinAlgError, match="2-th leading minor"):
+        oex.loss("Matern32", xdup, y[:, 0], bad[0], bad[1], bad[2])
+    handles = (C.c_void_p * cells)()
+    for c in range(cells):
+        handles[c] = make_handle(lib, n, d, "Matern32", False, xdup if c == 1 else x, y)
+    try:
+        units = np.zeros(cells, dtype=np.int32)
+        ref = oex.loss("Matern32", x, y[:, 0], good[0], good[1], good[2])
+        for rep in range(3):  # eager, capture, replay
+            thetas = np.ascontiguousarray(np.stack([good, bad, good]))
+            losses = np.zeros(cells)
+            assert lib.gprx_factorize_many(cells, handles, ptr(units), ptr(thetas), ALL, ptr(losses)) == _lib.GPRX_ENOTPD
+            assert np.isnan(losses[1]) and abs(losses[0] - ref) <= 1e-9 * abs(ref) and losses[2] == losses[0]
+        # the same handle factors a proper matrix afterwards
+        thetas = np.ascontiguousarray(np.stack([good, good, good]))
+        check(lib.gprx_factorize_many(cells, handles, ptr(units), ptr(thetas), ALL, ptr(losses)))
+        assert np.all(np.isfinite(losses))
     finally:
         for c in range(cells):
             lib.gprx_destroy(C.c_void_p(handles[c]))

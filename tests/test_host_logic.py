@@ -252,3 +252,16 @@ def test_lockstep_propagates_failures_without_deadlock(monkeypatch):
     g = gpr.GPRAS("RBF")
     with pytest.raises(np.linalg.LinAlgError):
         g.fit(x, y, None, optimization_method="adam", max_iter=3)
+
+
+def test_bench_launcher_counts_a_signalled_rank_as_a_failure():
+    """Popen.wait() is negative for a rank killed by a signal; the launcher's exit code must not be max() of the raw codes."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.worst_code([0, 0]) == 0
+    assert bench.worst_code([0, -6]) == 134 and bench.worst_code([0, -11, 3]) == 139
+    assert bench.worst_code([1, 124, 0]) == 124

@@ -86,3 +86,22 @@ def test_device_kmeans_init_time_at_n16384(capsys):
     with capsys.disabled():
         print(f"\n[kmeans init N=16384 d=10 M=50 on the device: {1e3 * dt:.1f} ms]")
     assert dt < 0.06  # (round 2: 120 ms with the seeding on the host; the verdict's bar is 15 ms on an idle box)
+
+
+def test_draw_sequence_check_against_the_installed_sklearn(monkeypatch):
+    """the device seeding hard-codes how scikit-learn >= 1.3 consumes RandomState(0); the once-per-process check must
+    accept the installed release and must notice a release that draws differently (then kmeans_centers seeds through sklearn)."""
+    from gpras_amd import kmeans
+
+    monkeypatch.setattr(kmeans, "_DRAWS_MATCH_SKLEARN", None)
+    assert kmeans.draws_match_installed_sklearn() is True
+    real = kmeans._draws
+
+    def other_release(n, m):  # e.g. an older scikit-learn: randint for the first centre, random_sample for the trials
+        trials, _, _ = real(n, m)
+        rs = np.random.RandomState(0)
+        return trials, int(rs.randint(n)), np.ascontiguousarray(rs.random_sample((max(m - 1, 1), trials)))
+
+    monkeypatch.setattr(kmeans, "_DRAWS_MATCH_SKLEARN", None)
+    monkeypatch.setattr(kmeans, "_draws", other_release)
+    assert kmeans.draws_match_installed_sklearn() is False

@@ -65,7 +65,7 @@ def test_exact_model_files_have_no_inducing_points(monkeypatch, tmp_path):
         assert g2.models[0].Z is None and g2.ard and np.array_equal(g2.models[0].lengthscales, g.models[0].lengthscales)
 
 
-def _reference_shaped_pickle(path, x, y, n_inducing, params):
+def _reference_shaped_pickle(path, x, y, n_inducing, params, kernel="RBF"):
     """A file laid out like the reference's (gpr.py:359-366): the parameter dicts hold objects of classes that live in
     ``gpflow`` / ``tensorflow`` modules.  SYNTHETIC: gpflow is not installed here, so the objects are built from stand-in
     modules registered only while pickling; their shape follows TensorFlow's ``ResourceVariable.__reduce__`` (a
@@ -96,7 +96,7 @@ def _reference_shaped_pickle(path, x, y, n_inducing, params):
             if name not in sys.modules:
                 added[name] = sys.modules[name] = mod if i == len(parts) else types.ModuleType(name)
     try:
-        d = {"kernel": "RBF", "data": {"x": x, "y": y}, "n_inducing": n_inducing,
+        d = {"kernel": kernel, "data": {"x": x, "y": y}, "n_inducing": n_inducing,
              "models": [{k: Parameter(v) for k, v in p.items()} for p in params]}
         with open(path, "wb") as f:
             pickle.dump(d, f)
@@ -123,6 +123,34 @@ def test_reference_written_file_is_read_without_gpflow(monkeypatch, tmp_path):
         assert m.lengthscales == pytest.approx(np.log1p(np.exp(-0.2)), rel=1e-15)
         assert m.noise == pytest.approx(1e-6 + np.log1p(np.exp(-1.0)), rel=1e-15)
         assert np.allclose(m.Z, u[".inducing_variable.Z"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("kernel, want", [("Matern12", "expanded"), ("Exponential", "expanded"), ("Matern52", "difference")])
+def test_reference_written_file_loads_with_gpflows_distance_form(monkeypatch, tmp_path, kernel, want):
+    """a model trained by gpflow and loaded through from_file must predict with gpflow's arithmetic where that matters
+    (Matern12 / Exponential: the difference form is 1.2e-8 / 2.5e-8 away) -- a file that carries no ``distance_form`` gets the
+    per-kernel default of ``GPRAS(kernel)``, not a blanket "difference"."""
+    monkeypatch.setattr(gpr, "Engine", OracleBackend)
+    rng = np.random.default_rng(4)
+    x, y = rng.standard_normal((30, 2)), rng.standard_normal((30, 1))
+    params = [{".kernel.variance": np.array(0.1), ".kernel.lengthscales": np.array(0.2), ".likelihood.variance": np.array(-2.0),
+               ".inducing_variable.Z": rng.standard_normal((4, 2))}]
+    path = tmp_path / "reference_gpr.pkl"
+    _reference_shaped_pickle(path, x, y, 4, params, kernel=kernel)
+    assert modelfile.load(path)["distance_form"] is None
+    g = gpr.GPRAS.from_file(path)
+    assert g.distance_form == want == gpr.GPRAS(kernel).distance_form
+    # a file of this package written before the key existed loads the same way
+    d = modelfile.model_dict(g)
+    del d["distance_form"]
+    with open(tmp_path / "old.pkl", "wb") as f:
+        pickle.dump(d, f)
+    assert gpr.GPRAS.from_file(tmp_path / "old.pkl").distance_form == want
+    # and an explicit choice survives a round trip
+    g2 = gpr.GPRAS(kernel, distance_form="difference")
+    g2.fit(x, y, 4, "grid", "adam", max_iter=1)
+    g2.to_file(tmp_path / "explicit.npz")
+    assert gpr.GPRAS.from_file(tmp_path / "explicit.npz").distance_form == "difference"
 
 
 def test_unrecoverable_parameters_fail_with_a_clear_message(tmp_path):

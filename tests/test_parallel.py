@@ -95,6 +95,53 @@ def test_file_rendezvous_ignores_stale_files_and_times_out_alone(tmp_path):
         file_rendezvous(prefix, 0, 2, "ok", lambda: b"x" * 128, timeout_s=0.5)
 
 
+def _late_rdv_worker(prefix, rank, world, delay, q):
+    import time
+
+    time.sleep(delay)
+    _rdv_worker(prefix, rank, world, "ok", q)
+
+
+def test_file_rendezvous_is_not_fooled_by_fresh_leftovers_of_another_launch(tmp_path):
+    """an earlier launch under the SAME explicit prefix died a minute ago and left `ready`, `ack` and `id` files that are
+    still fresh by their time stamps.  Rank 1 of the new launch starts late: rank 0 first reads the old `ready.1` ("ok"), but must
+    neither create an id on it nor may rank 1 take the old id -- the acks only match once everybody has read the current files."""
+    import multiprocessing as mp
+    import time
+
+    prefix = str(tmp_path / "rccl")
+    now = repr(time.time() - 60.0).encode()
+    for name, body in ((".ready.0", b"111.1\nok"), (".ready.1", b"222.2\nok"), (".ack.0", b"0" * 20), (".ack.1", b"0" * 20),
+                       (".id", b"0" * 20 + b"\n" + b"OLD" * 40)):
+        with open(prefix + name, "wb") as f:
+            f.write(now + b"\n" + body)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_late_rdv_worker, args=(prefix, r, 2, 1.5 * r, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    want = bytes(range(128)) + b"\n tail with a newline"
+    assert out == [(0, "id", want), (1, "id", want)]
+
+
+def test_reports_of_another_launch_do_not_count(tmp_path):
+    from gpras_amd.comm import FileExchange, report
+
+    import pytest
+
+    prefix = str(tmp_path / "rep")
+    with open(prefix + ".comm.1", "wb") as f:  # rank 1 of an earlier launch said yes
+        f.write(b"oldtag:1")
+    assert report(prefix, "comm", 0, 2, True, timeout_s=0.3, tag="newtag") == [True, None]
+    with open(prefix + ".fx.1.1", "wb") as f:
+        f.write(b"oldtag\n")
+    with pytest.raises(TimeoutError):
+        FileExchange(prefix, 0, 2, timeout_s=0.3, tag="newtag").barrier()
+
+
 def test_default_id_prefix_is_shared_by_siblings(monkeypatch):
     from gpras_amd.comm import default_id_prefix
 

@@ -25,9 +25,9 @@ for n, cells in ((1024, 512), (512, 512), (200, 300), (1000, 256)):
     units = np.arange(cells, dtype=np.int32)
     res = {}
     for mode in (-1, 1):
-        check(lib.gprx_set_tuning(b"cell_kernel", mode))
         h = C.c_void_p()
         check(lib.gprx_create(0, n, 8, 0, _lib.KERNEL_IDS["RBF"], 0, C.byref(h)))
+        check(lib.gprx_set_handle_tuning(h, b"cell_kernel", mode), h)  # (per handle: nothing process-wide to restore)
         check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
         losses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
         for _ in range(2):
@@ -50,6 +50,5 @@ for n, cells in ((1024, 512), (512, 512), (200, 300), (1000, 256)):
         "var_gap": float(np.max(np.abs(a[2] - b[2]) / a[2])), "status_ok": bool(np.all(a[4] == 0) and np.all(b[4] == 0)),
     }
     print(n, cells, out[f"n{n}_c{cells}"], flush=True)
-check(lib.gprx_set_tuning(b"cell_kernel", 0))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/cell_probe.json", "w"), indent=1)

@@ -1,18 +1,20 @@
 #!/bin/bash
-# PMC passes (one counter group per run, no tracing) over the one-workgroup-per-cell kernel at N = 1024 x 512 cells
+# PMC passes over the one-workgroup-per-cell kernel at N = 1024 x 512 cells (tools/batch_n1024.py): ONE counter group per run, no tracing
+# with --pmc, and FETCH_SIZE / WRITE_SIZE each in a pass of its own (together they exceed the TCC's 4 slots: FETCH_SIZE costs 3,
+# WRITE_SIZE 2 -- MI355X_MICROARCH.md, "rocprofv3 PMC slots"; round 3 asked for both in one pass and rocprofv3 aborted with error 38).
+#     bash tools/pmc_cell.sh [tag]        -> gpurun_out/<tag>_pmc_cell_kernel.json (+ kernel stats of an un-instrumented run)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=${1:-r04}
 export GPRX_CELL_KERNEL=1
-for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA" "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_cell/$tag -o c -- python3 tools/batch_n1024.py 1024 512 > gpurun_out/pmc_cell_$tag.log 2>&1 || { echo "failed: $set"; tail -3 gpurun_out/pmc_cell_$tag.log; }
+P="python3 tools/batch_n1024.py 1024 512"
+D=gpurun_out/pmc_cell_$tag
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o s -- $P > gpurun_out/${tag}_cell_stats.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 gpurun_out/${tag}_cell_stats.log; exit 1; }
+cp $(find $D/stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_n1024_batched_cell_kernel_kernel_stats.csv
+args=""
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $D/p$i -o c -- $P > gpurun_out/${tag}_pmc_cell_p$i.log 2>&1 || { echo "failed: $set"; tail -5 gpurun_out/${tag}_pmc_cell_p$i.log; exit 1; }
+  args="$args p$i=$D/p$i"
 done
-python3 - <<'PY'
-import csv, glob, collections
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_cell/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        if "potrf_cell_kernel" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]]["v"].append(float(r["Counter_Value"]))
-for k, v in sorted(acc.items()):
-    print(k, sum(v["v"]) / len(v["v"]), len(v["v"]))
-PY
+python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_cell_kernel.json $args
