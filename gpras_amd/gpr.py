@@ -25,11 +25,13 @@ from .kmeans import kmeans_centers
 from .model import GPModel
 from .optimizers import BATCHED_OPTIMIZERS, OPTIMIZERS
 
-# names that the reference maps to gpflow kernel classes (gpr.py:21-37).  Linear / Polynomial / Periodic
-# are listed there but cannot be constructed with (variance=, lengthscales=) at gpr.py:298 ("currently
-# not working" in the reference's own comments); they raise here too, at construction time.
-KERNEL_FACTORY = {name: name for name in KERNEL_IDS}
+# the names that the reference maps to gpflow kernel classes, in its order (gpr.py:21-37; pinned by tests/golden/gpr_ref_golden.npz).
+# Linear / Polynomial / Periodic are listed there but cannot be constructed with (variance=, lengthscales=) at gpr.py:298 ("currently
+# not working" in the reference's own comments): GPRAS(name) succeeds as in the reference, and the failure comes where the reference's
+# does -- when fit() builds the models.
 _REFERENCE_ONLY = ("Linear", "Polynomial", "Periodic")
+KERNEL_FACTORY = {name: name for name in ("Matern12", "Matern32", "Matern52", "RBF", "Linear", "Polynomial", "Periodic", "Exponential")}
+assert all(name in KERNEL_IDS for name in KERNEL_FACTORY if name not in _REFERENCE_ONLY)
 
 KernelType = Literal["Matern12", "Matern32", "Matern52", "RBF", "Linear", "Polynomial", "Periodic", "Exponential"]
 OptimizerType = Literal["two-stage", "adam", "L-BFGS-B", "stochastic", "diffential_evolution"]
@@ -55,11 +57,6 @@ class GPRAS:
         if distance_form is None:
             distance_form = DEFAULT_DISTANCE_FORM.get(kernel, "difference")
         self.distance_form = distance_form
-        if kernel in _REFERENCE_ONLY:
-            raise NotImplementedError(
-                f"kernel {kernel!r} is listed by the reference but cannot be built by its own fit() "
-                "(gpr.py:26-27, :298); only the stationary kernels are implemented"
-            )
         self.kernel = KERNEL_FACTORY[kernel]  # KeyError for unknown names, as the reference
         self.device = device
         self.models: list[GPModel] = []
@@ -150,6 +147,13 @@ class GPRAS:
         workers: int = 1,
     ) -> None:
         """Create one model per spatial mode using base model settings (gpr.py:277-308)."""
+        if self.kernel_str in _REFERENCE_ONLY:
+            # the reference fails at this point too: its kernel constructor call (gpr.py:298) passes variance= and lengthscales=, which
+            # gpflow's Linear / Polynomial / Periodic do not accept (TypeError there)
+            raise NotImplementedError(
+                f"kernel {self.kernel_str!r} is listed by the reference but cannot be built by its own fit() "
+                "(gpr.py:26-27, :298); only the stationary kernels are implemented"
+            )
         inducing = None if n_inducing is None else self._create_inducing(x, n_inducing, inducing_initializer)
         ini_length = np.mean(abs(x))
         self.ard = bool(ard)

@@ -96,11 +96,12 @@ def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
 
 def test_registries_match_the_reference():
     assert list(optimizers.OPTIMIZERS) == ["two-stage", "three-stage", "adam", "adadelta", "L-BFGS-B", "stochastic", "diffential_evolution"]
-    assert set(gpr.KERNEL_FACTORY) == {"Matern12", "Matern32", "Matern52", "RBF", "Exponential"}
+    assert list(gpr.KERNEL_FACTORY) == ["Matern12", "Matern32", "Matern52", "RBF", "Linear", "Polynomial", "Periodic", "Exponential"]  # gpr.py:21-29
     with pytest.raises(KeyError):
         gpr.GPRAS("Cosine")
+    g = gpr.GPRAS("Periodic")  # constructs, as in the reference; fails where the reference's kernel constructor call does (gpr.py:298)
     with pytest.raises(NotImplementedError):
-        gpr.GPRAS("Periodic")
+        g.fit(np.zeros((4, 2)), np.zeros((4, 1)), 2, "grid", "adam", max_iter=1)
     with pytest.raises(TypeError):  # adam has no default max_iter (gpr.py:147)
         optimizers.OPTIMIZERS["adam"](object())
 
