@@ -98,6 +98,7 @@ PROTOTYPES = {
     "gprx_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "gprx_set_handle_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "gprx_mfma_f64_peak": (C.c_int, [C.c_int, _dp]),
+    "gprx_exp_probe": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp]),
 }
 
 _lib = None

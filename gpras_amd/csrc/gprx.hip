@@ -2842,6 +2842,36 @@ int gprx_kmat(int device, int kernel_id, const double* a_dev, int64_t n1, const 
   return GPRX_OK;
 }
 
+// the kernel build's exponential (exp_nonpos_tab) / the gradient passes' (exp_nonpos) on an array: parity test of the function itself
+namespace {
+__global__ __launch_bounds__(256) void exp_probe_kernel(const double* __restrict__ x, double* __restrict__ out, int64_t n, int which) {
+  __shared__ double sTab[64];
+  exp_tab_fill(sTab);
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = which == 0 ? exp_nonpos_tab(x[i], sTab) : exp_nonpos(x[i]);
+}
+}  // namespace
+
+int gprx_exp_probe(int device, int which, const double* x, int64_t n, double* out) {
+  if (!x || !out || n < 0 || which < 0 || which > 1) return fail(nullptr, GPRX_EINVAL, "bad argument");
+  if (n == 0) return GPRX_OK;
+  HIPCHK(nullptr, hipSetDevice(device));
+  double *dx = nullptr, *dout = nullptr;
+  HIPCHK(nullptr, hipMalloc((void**)&dx, sizeof(double) * n));
+  hipError_t e = hipMalloc((void**)&dout, sizeof(double) * n);
+  if (e == hipSuccess) e = copy_sync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(exp_probe_kernel, dim3(2048), dim3(256), 0, util_stream(), dx, dout, n, which);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = copy_sync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost);
+  hipFree(dx);
+  if (dout) hipFree(dout);
+  HIPCHK(nullptr, e);
+  return GPRX_OK;
+}
+
 int gprx_gemm(int device, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* a_dev, int64_t lda,
               const double* b_dev, int64_t ldb, double beta, double* c_dev, int64_t ldc, int flags, int tile) {
   if (!a_dev || !b_dev || !c_dev) return fail(nullptr, GPRX_EINVAL, "null argument");

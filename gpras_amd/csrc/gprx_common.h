@@ -57,4 +57,52 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_amdgcn_ldexp(p, (int)n);  // n >= -1075 here: underflows gracefully to 0
 }
 
+// exp(x) for x <= 0 with a table: n = rint(x 64 / ln2), r = x - n ln2 / 64 (two-term constant, |r| <= ln2 / 128 = 0.0054), j = n mod 64,
+// m = floor(n / 64):  exp(x) = 2^m * T[j] * e^r,  T[j] = 2^(j/64) correctly rounded,  e^r - 1 = r + r^2 (1/2 + r/6 + r^2/24 + r^3/120)
+// (truncation r^6 / 720 <= 3.5e-17), combined as fma(T, e^r - 1, T): one rounding of T (half an ulp) and the final one.  13 fp64-rate
+// instructions instead of the 19 of exp_nonpos (the kernel build is bound by its fp64 VALU work next to its stores);
+// the 64-entry table sits in LDS (512 bytes = every bank pair exactly once: a wave's 64 different indices read without conflicts).
+// Used by the kernel-matrix build only; the gradient passes keep exp_nonpos.  Measured against numpy's exp on 1e7 arguments in
+// tests/test_gpu_blocks.py (<= 1 ulp).
+__constant__ double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0
+};
+constexpr double EXP_TAB_SCALE = 0x1.71547652b82fep+6;   // 64 / ln 2
+constexpr double EXP_TAB_C_HI = -0x1.62e42fef00000p-7;   // -(ln 2 / 64), 33 significant bits: n * C_HI is exact for |n| < 2^20
+constexpr double EXP_TAB_C_LO = -0x1.473de6af278edp-40;  // -(ln 2 / 64 - hi)
+
+__device__ __forceinline__ void exp_tab_fill(double* __restrict__ tab) {
+  if (threadIdx.x < 64) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+}
+
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ tab) {
+  x = x < -750.0 ? -750.0 : x;  // exp underflows to 0 below -745.2: n stays inside the exact range of the reduction for ANY x <= 0, -inf
+                                // included; a compare-select, not v_max_f64, so that a NaN argument stays a NaN
+  const double n = __builtin_rint(x * EXP_TAB_SCALE);
+  double r = __builtin_fma(n, EXP_TAB_C_HI, x);
+  r = __builtin_fma(n, EXP_TAB_C_LO, r);
+  double q = __builtin_fma(1.0 / 120.0, r, 1.0 / 24.0);
+  q = __builtin_fma(q, r, 1.0 / 6.0);
+  q = __builtin_fma(q, r, 0.5);
+  const double p = __builtin_fma(r * r, q, r);  // e^r - 1
+  const int ni = (int)n;
+  const double t = tab[ni & 63];
+  return __builtin_amdgcn_ldexp(__builtin_fma(t, p, t), ni >> 6);  // (x >= -745.2 gives ni >= -68800: underflows gracefully to 0 below)
+}
+
 }  // namespace gprx

@@ -17,23 +17,41 @@ namespace gprx {
 
 constexpr int KM_T = 64;   // tile edge
 constexpr int KM_DC = 8;   // coordinates staged per LDS pass
+// row stride of the transposed staging image sBt[k][point]: 66 doubles = 528 bytes (33 x 16: the 16-byte reads stay aligned).  With 64
+// the eight lanes of a staging store that differ in k sat 512 bytes apart -- one bank, an 8-way conflict (SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 0.24); with 66 a store instruction's 16-lane groups cover 16 distinct bank pairs.
+#ifdef GPRX_KMAT_NOPAD
+constexpr int KM_BT_LD = KM_T;
+#else
+constexpr int KM_BT_LD = KM_T + 2;
+#endif
+
+// the build's exponential: table + degree-5 polynomial (gprx_common.h exp_nonpos_tab; `tab` = the workgroup's LDS copy of 2^(j/64));
+// -DGPRX_KMAT_OLDEXP restores the degree-13 Taylor form for A/B measurements
+__device__ __forceinline__ double kmat_exp(double x, const double* __restrict__ tab) {
+#ifdef GPRX_KMAT_OLDEXP
+  return exp_nonpos(x);
+#else
+  return exp_nonpos_tab(x, tab);
+#endif
+}
 
 template <int KID>
-__device__ __forceinline__ double corr_g(double r2) {
+__device__ __forceinline__ double corr_g(double r2, const double* __restrict__ tab) {
   if constexpr (KID == 0) {
-    return exp_nonpos(-0.5 * r2);
+    return kmat_exp(-0.5 * r2, tab);
   } else {
     const double r = sqrt(fmax(r2, R2_FLOOR));
-    if constexpr (KID == 1) return exp_nonpos(-r);
+    if constexpr (KID == 1) return kmat_exp(-r, tab);
     if constexpr (KID == 2) {
       const double t = 1.7320508075688772 * r;
-      return (1.0 + t) * exp_nonpos(-t);
+      return (1.0 + t) * kmat_exp(-t, tab);
     }
     if constexpr (KID == 3) {
       const double t = 2.23606797749979 * r;
-      return (1.0 + t + (5.0 / 3.0) * r * r) * exp_nonpos(-t);
+      return (1.0 + t + (5.0 / 3.0) * r * r) * kmat_exp(-t, tab);
     }
-    return exp_nonpos(-0.5 * r);
+    return kmat_exp(-0.5 * r, tab);
   }
 }
 
@@ -102,6 +120,7 @@ struct KmatArgs {
   int64_t a_stride = 0, b_stride = 0;  // per-cell point sets (inducing inputs); 0: shared
   int diag_const = 0;                  // 1: keep diag_add as given (jitter) instead of the table's [1]
   int form = 0;                        // 0: difference form, 1: gpflow's expanded form (see the header comment)
+  int tri = 0;                         // mode 1 launched on the T (T + 1) / 2 lower tiles only (launch_kmat sets it): blockIdx.x counts them row by row
 };
 constexpr int CELL_PAR = 72;
 constexpr int CELL_PAR_LS = 8;
@@ -111,9 +130,21 @@ constexpr int CELL_PAR_LS = 8;
 // FORM (compile time: the default difference form keeps the registers and code of the kernel it always was -- as a run-time
 // branch the expanded form's extra accumulators cost the default path 50 %: 2.8 -> 4.2 ms for 128 cells of N = 4096)
 template <int KID, int FORM = 0>
-__device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC], double (*sBt)[KM_T]) {
-  const int ti = bx / p.tiles_n, tj = bx % p.tiles_n;
-  if (p.mode == 1 && tj > ti) return;
+__device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC], double (*sBt)[KM_BT_LD], double* __restrict__ sTab) {
+  int ti, tj;
+  if (p.tri) {
+    // bx = ti (ti + 1) / 2 + tj, tj <= ti: only the tiles the Cholesky reads are launched (the full T x T grid returned at once in 49 %
+    // of its workgroups).  ti from the float square root, corrected by one step either way.
+    ti = (int)((__builtin_sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
+    if ((ti + 1) * (ti + 2) / 2 <= bx) ++ti;
+    if (ti * (ti + 1) / 2 > bx) --ti;
+    tj = bx - ti * (ti + 1) / 2;
+  } else {
+    ti = bx / p.tiles_n;
+    tj = bx % p.tiles_n;
+    if (p.mode == 1 && tj > ti) return;
+  }
+  exp_tab_fill(sTab);  // (visible after the first staging barrier below: every path has d >= 1)
   const int i0 = ti * KM_T, j0 = tj * KM_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cp = lane & 31, rsub = lane >> 5;
@@ -229,11 +260,13 @@ __device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC
       v.x = p.variance * acc[it][0];
       v.y = p.variance * acc[it][1];
 #else
-      v.x = p.variance * corr_g<KID>(acc[it][0]);
-      v.y = p.variance * corr_g<KID>(acc[it][1]);
+      v.x = p.variance * corr_g<KID>(acc[it][0], sTab);
+      v.y = p.variance * corr_g<KID>(acc[it][1], sTab);
 #endif
 #ifdef GPRX_KMAT_NOSTORE
       if (v.x == 123.456) *reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j0 + 2 * cp) = v;
+#elif defined(GPRX_KMAT_NT)
+      __builtin_nontemporal_store(v, reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j0 + 2 * cp));
 #else
       *reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j0 + 2 * cp) = v;
 #endif
@@ -247,8 +280,8 @@ __device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC
     if (i >= p.n1p || j >= p.n2p) continue;
     d2 v;
     const bool vi = i < p.n1;
-    v.x = (vi && j < p.n2) ? p.variance * corr_g<KID>(acc[it][0]) : 0.0;
-    v.y = (vi && j + 1 < p.n2) ? p.variance * corr_g<KID>(acc[it][1]) : 0.0;
+    v.x = (vi && j < p.n2) ? p.variance * corr_g<KID>(acc[it][0], sTab) : 0.0;
+    v.y = (vi && j + 1 < p.n2) ? p.variance * corr_g<KID>(acc[it][1], sTab) : 0.0;
     if (i == j) v.x += (vi && j < p.n2) ? p.diag_add : p.pad_diag;
     if (i == j + 1) v.y += (vi && j + 1 < p.n2) ? p.diag_add : p.pad_diag;
     *reinterpret_cast<d2*>(p.out + (int64_t)i * p.ld + j) = v;
@@ -258,26 +291,32 @@ __device__ __forceinline__ void kmat_body(KmatArgs p, int bx, double (*sA)[KM_DC
 template <int KID, int FORM = 0>
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
-  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
-  kmat_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt);
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_BT_LD];
+  __shared__ __attribute__((aligned(16))) double sTab[64];
+  kmat_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt, sTab);
 }
 // Two builds in one launch (the sparse model's Kuf and Kuu): workgroups [0, first) take p, the rest q.  A dependent launch
 // costs ~10 us on this part whatever it computes.
 template <int KID, int FORM = 0>
 __global__ __launch_bounds__(256) void kmat_pair_kernel(KmatArgs p, KmatArgs q, int first) {
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
-  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
+  __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_BT_LD];
+  __shared__ __attribute__((aligned(16))) double sTab[64];
   if ((int)blockIdx.x < first)
-    kmat_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt);
+    kmat_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt, sTab);
   else
-    kmat_body<KID, FORM>(q, (int)blockIdx.x - first, sA, sBt);
+    kmat_body<KID, FORM>(q, (int)blockIdx.x - first, sA, sBt, sTab);
 }
 
 inline hipError_t launch_kmat(hipStream_t st, int kid, KmatArgs p, int batch = 1) {
   const int tiles_m = (p.n1p + KM_T - 1) / KM_T;
   p.tiles_n = (p.n2p + KM_T - 1) / KM_T;
   if (tiles_m == 0 || p.tiles_n == 0) return hipSuccess;
-  dim3 grid(tiles_m * p.tiles_n, batch), block(256);
+  p.tri = 0;
+#ifndef GPRX_KMAT_FULLGRID
+  if (p.mode == 1 && tiles_m == p.tiles_n && tiles_m <= 4096) p.tri = 1;  // (the float decode of the tile index is exact far beyond 4096 (4096 + 1) / 2)
+#endif
+  dim3 grid(p.tri ? tiles_m * (tiles_m + 1) / 2 : tiles_m * p.tiles_n, batch), block(256);
 #define GPRX_KMAT_CASE(K_)                                                          \
   case K_:                                                                          \
     if (p.form)                                                                     \

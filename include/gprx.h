@@ -367,6 +367,10 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
 int gprx_set_tuning(const char* key, int value);
 int gprx_set_handle_tuning(gprx_handle h, const char* key, int value);
 
+/* The device exponentials on an array of HOST values (parity tests): which = 0: the kernel-matrix build's exp (2^(j/64) table in LDS +
+ * degree-5 polynomial, arguments <= 0), which = 1: the degree-13 form the gradient passes use.  x, out: n host doubles. */
+int gprx_exp_probe(int device, int which, const double* x, int64_t n, double* out);
+
 /* measured back-to-back v_mfma_f64_16x16x4_f64 rate of the whole chip, TFLOP/s */
 int gprx_mfma_f64_peak(int device, double* tflops);
 

@@ -97,6 +97,54 @@ def test_kmat_vs_oracle(lib, kernel, ard):
     assert np.array_equal(np.diag(got)[:n1], np.full(n1, 1.7 + 0.25))  # r2(a, a) == 0 exactly
 
 
+@pytest.mark.parametrize("n", [64, 100, 448, 1000, 2100])
+def test_kmat_lower_tiles_only_launch(lib, n):
+    """mode 1 (what the Cholesky reads) launches only the T (T + 1) / 2 tiles on or below the diagonal, decoded from the linear workgroup
+    index (kmat.h `tri`): every such tile equals the all-tiles build (mode 2) bit for bit, no tile above the diagonal is touched."""
+    rng = np.random.default_rng(5)
+    d = 3
+    a = rng.standard_normal((n, d))
+    npad = -(-n // 64) * 64
+    inv = np.full(d, 0.9)
+    dA = DeviceBuffer.from_array(a)
+    full, low = DeviceBuffer(npad * npad * 8), DeviceBuffer.from_array(np.full((npad, npad), -7.0))
+    check(lib.gprx_kmat(0, 0, dA.ptr, n, dA.ptr, n, d, ptr(inv), 1.3, 0.5, full.ptr, npad, npad, npad, 2))
+    check(lib.gprx_kmat(0, 0, dA.ptr, n, dA.ptr, n, d, ptr(inv), 1.3, 0.5, low.ptr, npad, npad, npad, 1))
+    f, g = full.to_array((npad, npad)), low.to_array((npad, npad))
+    t = npad // 64
+    for ti in range(t):
+        for tj in range(t):
+            blk = g[64 * ti:64 * ti + 64, 64 * tj:64 * tj + 64]
+            if tj <= ti:
+                assert np.array_equal(blk, f[64 * ti:64 * ti + 64, 64 * tj:64 * tj + 64]), (ti, tj)
+            else:
+                assert np.all(blk == -7.0), (ti, tj)
+
+
+def test_kernel_build_exponential_within_one_ulp_of_numpy(lib):
+    """the kernel build's exp (2^(j/64) table + degree-5 polynomial, gprx_common.h exp_nonpos_tab) against the oracle's
+    np.exp on 1e7 arguments over the whole range of non-positive kernel arguments: <= 1 ulp everywhere, exact at the ends."""
+    rng = np.random.default_rng(2026)
+    x = np.concatenate([-rng.uniform(0.0, 40.0, 6_000_000), -rng.uniform(0.0, 1.0, 2_000_000), -np.exp(rng.uniform(-40.0, 6.6, 2_000_000)),
+                        [0.0, -0.0, -1e-300, -745.0, -745.2, -746.0, -1000.0, -1e300, -np.inf]])
+    got = np.empty_like(x)
+    check(lib.gprx_exp_probe(0, 0, ptr(x), x.size, ptr(got)))
+    with np.errstate(under="ignore"):
+        ref = np.exp(x)
+    ulp = np.spacing(ref)
+    err = np.abs(got - ref) / ulp
+    assert np.max(err) <= 1.0, (float(np.max(err)), float(x[np.argmax(err)]))
+    assert got[-9] == 1.0 and got[-8] == 1.0 and got[-7] == 1.0 and np.all(got[-3:] == 0.0)
+    assert np.mean(err > 0) < 0.3  # (mostly np.exp's value; measured 0.22 -- the rest one ulp beside it)
+    nan = np.array([np.nan])
+    out = np.zeros(1)
+    check(lib.gprx_exp_probe(0, 0, ptr(nan), 1, ptr(out)))
+    assert np.isnan(out[0])
+    # the degree-13 form of the gradient passes, for the record (same bar)
+    check(lib.gprx_exp_probe(0, 1, ptr(x[:1_000_000]), 1_000_000, ptr(got[:1_000_000])))
+    assert np.max(np.abs(got[:1_000_000] - ref[:1_000_000]) / ulp[:1_000_000]) <= 1.0
+
+
 @pytest.mark.parametrize("n,extra", [(64, 0), (128, 64), (448, 64), (1024, 128)])
 def test_potrf_vs_scipy(lib, n, extra):
     rng = np.random.default_rng(n)
