@@ -11,7 +11,10 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "libgprx.so"
+import os
+
+# (GPRX_LIBRARY: another build of the same library, e.g. an experiment compiled with -D flags -- development A/B runs only)
+LIB_PATH = Path(os.environ["GPRX_LIBRARY"]) if os.environ.get("GPRX_LIBRARY") else Path(__file__).resolve().parent / "libgprx.so"
 
 GPRX_OK, GPRX_EINVAL, GPRX_ENOTPD, GPRX_EHIP, GPRX_ENOMEM, GPRX_ESTATE, GPRX_ERCCL = range(7)
 UNIQUE_ID_BYTES = 128

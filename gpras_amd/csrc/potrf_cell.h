@@ -27,6 +27,15 @@ namespace gprx {
 #endif
 constexpr int CELL_NI = GPRX_CELL_NI;
 
+// threadIdx.x behind an opaque move: everything a phase derives from it (lane offsets, swizzles, buffer offsets) is computed INSIDE the
+// phase.  Without it the compiler hoists those lane-dependent values of every phase out of the kernel's column loop and keeps them all
+// live at once: the column-pair kernel, whose phases fit into 252 / 177 / 156 / 190 registers one by one, came out with 340 B of scratch.
+__device__ __forceinline__ int cell_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 struct CellArgs {
   double* A;         // cell 0; cells are `cs` doubles apart
   int64_t lda;
@@ -44,7 +53,7 @@ __device__ __forceinline__ int cell_diag(double* __restrict__ Ajj, int64_t lda, 
   c.sIn = smem;
   c.sX = smem + 128 * PSUB;
   double* sT = smem + 2 * 128 * PSUB;
-  c.tid = threadIdx.x;
+  c.tid = cell_tid();
   const int lane = c.tid & 63;
   c.wave = c.tid >> 6;
   c.g = lane >> 4;
@@ -95,7 +104,7 @@ __device__ __forceinline__ int cell_diag(double* __restrict__ Ajj, int64_t lda, 
 // does with the tile it re-reads from memory -- same operands, same products: the factor is the two-pass kernel's bit for bit,
 // with one store and one load of every tile less (8.7 of ~44 MB per N = 1024 cell).
 __device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int ni, int j, double* __restrict__ smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
   const unsigned ldb = (unsigned)p.lda * 8u;
   double* sA = smem;
@@ -209,7 +218,7 @@ __device__ __forceinline__ void cell_panel_fused(const TileCtx& p, int i0, int n
 // general panel's one-step-ahead prefetch left a memory round trip exposed in every step of this short dependent pass: 120 steps
 // per N = 1024 cell).  Same products in the same order as dag_panel<false> on this tile: bit-identical.
 __device__ __forceinline__ void cell_diag_update(const TileCtx& p, int j, double* __restrict__ smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
   const unsigned ldb = (unsigned)p.lda * 8u;
   double* sA = smem;
@@ -320,6 +329,306 @@ __global__ __launch_bounds__(256, 2) void potrf_cell_kernel(CellArgs p) {
   if (threadIdx.x == 0 && first_bad > 0) atomicCAS(p.info + (int64_t)blockIdx.x * p.info_stride, 0, p.col_base + first_bad);
 }
 
+// ---- column PAIRS (round 4): the operand stream halved -----------------------------------------------------------------------------
+// Measured on the kernel above (profiles/r04_pmc_cell_kernel.json, N = 1024 x 512 cells): 52.8 MB of HBM traffic per cell (45.7 read +
+// 5.9 written; the matrix itself is 4.2 MB) at 4.56 TB/s -- the kernel is HBM-bound, and three quarters of those bytes are the operand
+// tiles of the left-looking update, 1.5 tile loads per 64 x 64 x 64 product (two row tiles sharing one B tile).  Here two block
+// columns (j, j + 1) are updated TOGETHER: a group of two row tiles against the two column tiles is one 128 x 128 product
+//     acc(t, c) = sum_{k < 64 j} L(i0 + t, k) L(j + c, k)^T        t, c in {0, 1}   (cell2_stream)
+// whose operands are two contiguous 128-row panels of L, streamed global -> LDS by LDS-DMA in 16-deep stages (double-buffered: the
+// loop of gemm_f64.h with a 128 x 128 workgroup tile, every wave holding the 32 x 32 quarter it owns of each of the four 64 x 64
+// tiles, so each tile sits in the accumulator layout the solve steps below expect): 1.0 tile loads per product and no staging
+// registers.  Then, per row tile, on LDS images only:
+//     L(i, j)     = (A(i, j)     - acc(t, 0)) L(j, j)^-T
+//     acc(t, 1)  += L(i, j) L(j + 1, j)^T                          (the one term of column j + 1 that column j's result feeds)
+//     L(i, j + 1) = (A(i, j + 1) - acc(t, 1)) L(j + 1, j + 1)^-T
+// The accumulation order of every tile is that of the single-column kernel (k ascending in stages of 16, instruction jj takes
+// k = k0 + 4 g + jj), and the operands are the same values: the factor equals potrf_cell_kernel_t's BIT FOR BIT (tested).
+constexpr int CELL2_STAGE = 4 * NB * GEMM_BK;  // doubles per stage: A image [128][16] | B image [128][16]
+static_assert(2 * CELL2_STAGE <= DAG_SMEM, "the two stages fit into the LDS of the single-column kernel");
+
+// a 64 x 64 block stored with leading dimension `ld` -> the four [64][16] stage images at `img`, by LDS-DMA (lane l of wave w fills row
+// 8 (4 i + w) + (l >> 3), LDS chunk l & 7 = global chunk (l & 7) ^ kc_swz(row): the involution the fragment reads apply)
+__device__ __forceinline__ void cell2_dma_block(const double* __restrict__ src, int64_t ld, double* __restrict__ img, int wave_u, int lane) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = (i * 4 + wave_u) * 8;
+      const int row = rbase + (lane >> 3);
+      glds16(src + (int64_t)row * ld + s * GEMM_BK + 2 * ((lane & 7) ^ kc_swz(row)), img + s * (NB * GEMM_BK) + rbase * GEMM_BK);
+    }
+}
+
+// The streaming product of a pass: acc(t, c) += sum_{k < K} A(64 t + ., k) B(64 c + ., k)^T, A = NI row tiles at Arow, B = the two
+// tiles at Brow, both with leading dimension lda; SAME: A and B are the same panel (the pair's own rows: one image serves both, and
+// the tile above the diagonal, (t, c) = (0, 1), is left out).  16-deep stages, LDS-DMA, two buffers, one barrier per stage.
+template <int NI, bool SAME>
+__device__ __forceinline__ void cell2_stream(d4 (&acc)[NI][2][2][2], const double* __restrict__ Arow, const double* __restrict__ Brow, int64_t lda, int K,
+                                             double* __restrict__ smem, int lane, int wave_u, int wm, int wn, int g, int r) {
+  const int swz = kc_swz(r);
+  auto dma_fill = [&](int k0, int buf) {
+    double* sa = smem + buf * CELL2_STAGE;
+    double* sb = sa + 2 * NB * GEMM_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = (i * 4 + wave_u) * 8;
+      const int row = rbase + (lane >> 3);
+      const int chunk = 2 * ((lane & 7) ^ kc_swz(row));
+      if (!SAME && i < 2 * NI) glds16(Arow + (int64_t)row * lda + k0 + chunk, sa + rbase * GEMM_BK);
+      glds16(Brow + (int64_t)row * lda + k0 + chunk, sb + rbase * GEMM_BK);
+    }
+  };
+  auto stage = [&](int k0, int buf) {
+#ifndef GPRX_CELL2_NODMA
+    if (k0 + GEMM_BK < K) dma_fill(k0 + GEMM_BK, buf ^ 1);  // (every wave left buffer buf ^ 1 at the previous barrier)
+#endif
+    const double* sb = smem + buf * CELL2_STAGE + 2 * NB * GEMM_BK;
+    const double* sa = SAME ? sb : smem + buf * CELL2_STAGE;
+    double fa[NI][2][4], fb[2][2][4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = t * NB + wm * 32 + a * 16 + r;
+        const d2 lo = *reinterpret_cast<const d2*>(sa + row * GEMM_BK + 2 * ((2 * g) ^ swz));
+        const d2 hi = *reinterpret_cast<const d2*>(sa + row * GEMM_BK + 2 * ((2 * g + 1) ^ swz));
+        fa[t][a][0] = lo.x; fa[t][a][1] = lo.y; fa[t][a][2] = hi.x; fa[t][a][3] = hi.y;
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int col = c * NB + wn * 32 + b * 16 + r;
+        const d2 lo = *reinterpret_cast<const d2*>(sb + col * GEMM_BK + 2 * ((2 * g) ^ swz));
+        const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_BK + 2 * ((2 * g + 1) ^ swz));
+        fb[c][b][0] = lo.x; fb[c][b][1] = lo.y; fb[c][b][2] = hi.x; fb[c][b][3] = hi.y;
+      }
+#ifdef GPRX_CELL2_NOMMA
+    acc[0][0][0][0][0] += fa[0][0][0] + fb[0][0][0] + fa[NI - 1][1][3] + fb[1][1][3];
+#else
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int t = 0; t < NI; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (SAME && t == 0 && c == 1) continue;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][c][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[t][a][jj], fb[c][b][jj], acc[t][c][a][b], 0, 0, 0);
+        }
+#endif
+    __syncthreads();  // (vmcnt(0): this wave's DMA of the next stage has landed; then every wave's)
+  };
+  if (K > 0) {
+    dma_fill(0, 0);
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 2 * GEMM_BK) {
+      stage(k0, 0);
+      stage(k0 + GEMM_BK, 1);  // (K is a multiple of 64)
+    }
+  }
+}
+
+// what the solve steps share: accumulator layout <-> A stage images, the residual C - sum, tile stores
+struct Cell2Lane {
+  int wm, wn, g, r;
+  unsigned ldb, off_cd;
+};
+__device__ __forceinline__ void cell2_to_image(double* __restrict__ sA, const d4 (&v)[2][2], const Cell2Lane& q) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = q.wm * 32 + a * 16 + q.g + 4 * e, col = q.wn * 32 + b * 16 + q.r;
+        sA[(col >> 4) * (NB * GEMM_BK) + row * GEMM_BK + ((((col & 15) >> 1) ^ kc_swz(row)) * 2) + (col & 1)] = v[a][b][e];
+      }
+}
+// v <- C - v for the tile at `tile` (one rounding, as gemm_f64: fma(1, C, -1 * sum))
+__device__ __forceinline__ void cell2_residual(d4 (&v)[2][2], const double* __restrict__ tile, const Cell2Lane& q) {
+  const __amdgpu_buffer_rsrc_t rc = dag_rsrc(tile);
+  double cold[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cold[a][b][e] = ld1_sc1<false>(rc, q.off_cd, (unsigned)(a * 16 + 4 * e) * q.ldb + (unsigned)b * 128u);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[a][b][e] = __builtin_fma(1.0, cold[a][b][e], -1.0 * v[a][b][e]);
+}
+__device__ __forceinline__ void cell2_store(const d4 (&v)[2][2], double* __restrict__ tile, const Cell2Lane& q) {
+  const __amdgpu_buffer_rsrc_t rc = dag_rsrc(tile);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st1_sc1<false>(rc, q.off_cd, v[a][b][e], (unsigned)(a * 16 + 4 * e) * q.ldb + (unsigned)b * 128u);
+}
+__device__ __forceinline__ void cell2_zero(d4 (&v)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) v[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+}
+
+// row tiles i0 .. i0 + NI - 1 (all below tile row j + 1) of the block columns j and j + 1
+template <int NI>
+__device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, double* __restrict__ smem) {
+  const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  Cell2Lane q;
+  q.wm = wave >> 1, q.wn = wave & 1, q.g = lane >> 4, q.r = lane & 15;
+  q.ldb = (unsigned)p.lda * 8u;
+  q.off_cd = (unsigned)(q.wm * 32 + q.g) * q.ldb + (unsigned)(q.wn * 32 + q.r) * 8u;
+  const int swz = kc_swz(q.r);
+  d4 acc[NI][2][2][2];
+#pragma unroll
+  for (int t = 0; t < NI; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cell2_zero(acc[t][c]);
+    }
+  cell2_stream<NI, false>(acc, p.A + (int64_t)i0 * NB * p.lda, p.A + (int64_t)j * NB * p.lda, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r);
+  // ---- the solve steps: one B image at a time (L(j,j)^-1, then L(j+1,j), then L(j+1,j+1)^-1), every row tile against it ----
+  // (the streaming loop's last barrier has passed: both stage buffers are free)
+  double* sA = smem;
+  double* sB = smem + NB * NB;
+  auto tile = [&](int i, int jc) { return p.A + (int64_t)i * NB * p.lda + (int64_t)jc * NB; };
+  // E1: L(i, j) = (A(i, j) - acc(t, 0)) L(j, j)^-T
+  cell2_dma_block(p.inv_diag + (int64_t)j * NB * NB, NB, sB, wave_u, lane);
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    cell2_residual(acc[t][0], tile(i0 + t, j), q);
+    cell2_to_image(sA, acc[t][0], q);
+    __syncthreads();  // (the first one also waits for the B image's DMA)
+    cell2_zero(acc[t][0]);
+    dag_mma64(acc[t][0], sA, sB, q.wm, q.wn, q.g, q.r, swz);
+    cell2_store(acc[t][0], tile(i0 + t, j), q);
+    lds_barrier();  // the A image is free again
+  }
+  // E2: acc(t, 1) += L(i, j) L(j + 1, j)^T
+  cell2_dma_block(tile(j + 1, j), p.lda, sB, wave_u, lane);
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    cell2_to_image(sA, acc[t][0], q);
+    __syncthreads();
+    dag_mma64(acc[t][1], sA, sB, q.wm, q.wn, q.g, q.r, swz);
+    lds_barrier();
+  }
+  // E3: L(i, j + 1) = (A(i, j + 1) - acc(t, 1)) L(j + 1, j + 1)^-T
+  cell2_dma_block(p.inv_diag + (int64_t)(j + 1) * NB * NB, NB, sB, wave_u, lane);
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    cell2_residual(acc[t][1], tile(i0 + t, j + 1), q);
+    cell2_to_image(sA, acc[t][1], q);
+    __syncthreads();
+    cell2_zero(acc[t][1]);
+    dag_mma64(acc[t][1], sA, sB, q.wm, q.wn, q.g, q.r, swz);
+    cell2_store(acc[t][1], tile(i0 + t, j + 1), q);
+    lds_barrier();
+  }
+}
+
+// The pair's own three tiles (j, j), (j + 1, j), (j + 1, j + 1): ONE streaming product of the 128-row panel with itself (what the
+// single-column kernel does as three latency-bound passes of one tile product per step: the diagonal update of j, update + solve of
+// (j + 1, j), the diagonal update of j + 1), then the two chains and the solve between them.  Returns the failing pivot (1-based,
+// within the pair's 128 columns) or 0.
+__device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, double* __restrict__ smem) {
+  const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  Cell2Lane q;
+  q.wm = wave >> 1, q.wn = wave & 1, q.g = lane >> 4, q.r = lane & 15;
+  q.ldb = (unsigned)p.lda * 8u;
+  q.off_cd = (unsigned)(q.wm * 32 + q.g) * q.ldb + (unsigned)(q.wn * 32 + q.r) * 8u;
+  const int swz = kc_swz(q.r);
+  d4 acc[2][2][2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) cell2_zero(acc[t][c]);
+  const double* Prow = p.A + (int64_t)j * NB * p.lda;
+  cell2_stream<2, true>(acc, Prow, Prow, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r);
+  auto tile = [&](int i, int jc) { return p.A + (int64_t)i * NB * p.lda + (int64_t)jc * NB; };
+  double* inv = const_cast<double*>(p.inv_diag);
+  double* sA = smem;
+  double* sB = smem + NB * NB;
+  // (j, j): the updated tile goes back to memory, the chain factors it there
+  cell2_residual(acc[0][0], tile(j, j), q);
+  cell2_store(acc[0][0], tile(j, j), q);
+  __syncthreads();
+  int bad = cell_diag(tile(j, j), p.lda, inv + (int64_t)j * NB * NB, smem);
+  __syncthreads();
+  // (j + 1, j) = (A - sum) L(j, j)^-T, then its square into the sum of (j + 1, j + 1)
+  cell2_dma_block(p.inv_diag + (int64_t)j * NB * NB, NB, sB, wave_u, lane);
+  cell2_residual(acc[1][0], tile(j + 1, j), q);
+  cell2_to_image(sA, acc[1][0], q);
+  __syncthreads();
+  cell2_zero(acc[1][0]);
+  dag_mma64(acc[1][0], sA, sB, q.wm, q.wn, q.g, q.r, swz);
+  cell2_store(acc[1][0], tile(j + 1, j), q);
+  lds_barrier();
+  cell2_to_image(sA, acc[1][0], q);
+  lds_barrier();
+  dag_mma64(acc[1][1], sA, sA, q.wm, q.wn, q.g, q.r, swz);
+  cell2_residual(acc[1][1], tile(j + 1, j + 1), q);
+  cell2_store(acc[1][1], tile(j + 1, j + 1), q);
+  __syncthreads();
+  const int bad2 = cell_diag(tile(j + 1, j + 1), p.lda, inv + (int64_t)(j + 1) * NB * NB, smem);
+  if (bad == 0 && bad2 > 0) bad = NB + bad2;
+  return bad;
+}
+
+#ifndef GPRX_CELL2_OCC
+#define GPRX_CELL2_OCC 2
+#endif
+__global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[DAG_SMEM];
+  const int64_t off = (int64_t)blockIdx.x * p.cs;
+  const TileCtx tc{p.A + off, p.lda, p.inv_diag + off};
+  int first_bad = 0;
+  for (int j = 0; j < p.T; j += 2) {
+    if (j + 1 >= p.T) {  // a last single column: the single-column passes
+      if (j > 0) {
+        cell_diag_update(tc, j, smem);
+        __syncthreads();
+      }
+      const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
+      if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
+      __syncthreads();
+      for (int i0 = j + 1; i0 < p.R; i0 += CELL_NI) {
+        cell_panel_fused(tc, i0, p.R - i0 < CELL_NI ? p.R - i0 : CELL_NI, j, smem);
+        __syncthreads();
+      }
+      break;
+    }
+    const int bad = cell2_diag_pair(tc, j, smem);
+    if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
+    __syncthreads();
+#ifndef GPRX_CELL2_NOROWS
+    int i0 = j + 2;
+    for (; i0 + 1 < p.R; i0 += 2) {
+      cell2_rows<2>(tc, i0, j, smem);
+      __syncthreads();
+    }
+    if (i0 < p.R) {  // an odd tile at the end (the right-hand-side rows when T is even): a 64 x 128 pass of its own, nothing duplicated
+      cell2_rows<1>(tc, i0, j, smem);
+      __syncthreads();
+    }
+#endif
+  }
+  if (threadIdx.x == 0 && first_bad > 0) atomicCAS(p.info + (int64_t)blockIdx.x * p.info_stride, 0, p.col_base + first_bad);
+}
+
 // `batch` matrices of np x np (+ extra right-hand-side rows), cs doubles apart; info words info_stride ints apart (zeroed by the caller)
 inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info, int batch, int64_t cs,
                               int info_stride, int col_base = 0) {
@@ -334,10 +643,13 @@ inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, in
   a.info_stride = info_stride;
   a.col_base = col_base;
   static const bool two_pass = getenv("GPRX_CELL_TWO_PASS") && atoi(getenv("GPRX_CELL_TWO_PASS")) != 0;
+  static const bool single_column = getenv("GPRX_CELL_SINGLE_COLUMN") && atoi(getenv("GPRX_CELL_SINGLE_COLUMN")) != 0;  // (round 3's kernel, for A/B)
   if (two_pass)
     hipLaunchKernelGGL(potrf_cell_kernel, dim3(batch), dim3(256), 0, st, a);
-  else
+  else if (single_column)
     hipLaunchKernelGGL(potrf_cell_kernel_t<true>, dim3(batch), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(potrf_cell2_kernel, dim3(batch), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -120,28 +120,32 @@ from gpras_amd._lib import check, ptr
 from gpras_amd.synth import make_regression
 from oracle import transforms as otr
 lib = _lib.load()
-n, d, cells = 700, 4, 10
-x, y, _ = make_regression(n, d, n_outputs=cells, n_test=4, config=2, unit=n)
-base = np.array(otr.unconstrain(1.0, float(np.mean(np.abs(x))), 0.5), dtype=np.float64)
-thetas = np.ascontiguousarray(base[None, :] + np.random.default_rng(1).uniform(-0.2, 0.2, size=(cells, 3)))
-units = np.arange(cells, dtype=np.int32)
-h = C.c_void_p()
-check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h)))
-check(lib.gprx_set_handle_tuning(h, b"cell_kernel", 1), h)
-check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
-losses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
-check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(losses), ptr(status)), h)
-lib.gprx_destroy(h)
-print(json.dumps([float.hex(v) for v in losses]))
+out = []
+for n, d, cells in ((700, 4, 10), (1024, 8, 6), (64, 2, 3), (130, 3, 7), (960, 5, 4)):  # 11, 16, 1, 3 and 15 block columns
+    x, y, _ = make_regression(n, d, n_outputs=cells, n_test=4, config=2, unit=n)
+    base = np.array(otr.unconstrain(1.0, float(np.mean(np.abs(x))), 0.5), dtype=np.float64)
+    thetas = np.ascontiguousarray(base[None, :] + np.random.default_rng(1).uniform(-0.2, 0.2, size=(cells, 3)))
+    units = np.arange(cells, dtype=np.int32)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h)))
+    check(lib.gprx_set_handle_tuning(h, b"cell_kernel", 1), h)
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), cells), h)
+    losses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
+    check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(losses), ptr(status)), h)
+    lib.gprx_destroy(h)
+    out += [float.hex(v) for v in losses]
+print(json.dumps(out))
 """
 
 
-def test_fused_cell_kernel_equals_its_two_pass_form_bit_for_bit():
-    """cell_panel_fused (update and solve of a tile in one pass) performs the products of the two-pass kernel on the same operands."""
+def test_cell_kernel_forms_agree_bit_for_bit():
+    """Three forms of the one-workgroup-per-cell kernel -- two passes per block column, update + solve fused per tile (round 3), and the
+    column-pair kernel (round 4: two block columns per pass on LDS-DMA operand panels, potrf_cell.h cell2_rows) -- perform the same tile
+    products on the same operands in the same accumulation order: the losses are equal to the last bit."""
     outs = []
-    for two_pass in ("0", "1"):
-        res = subprocess.run([sys.executable, "-c", TWO_PASS.format(root=ROOT)], capture_output=True, text=True, timeout=600,
-                             env=dict(os.environ, GPRX_CELL_TWO_PASS=two_pass))
+    for env in ({"GPRX_CELL_TWO_PASS": "1"}, {"GPRX_CELL_SINGLE_COLUMN": "1"}, {}):
+        base = {k: v for k, v in os.environ.items() if k not in ("GPRX_CELL_TWO_PASS", "GPRX_CELL_SINGLE_COLUMN")}
+        res = subprocess.run([sys.executable, "-c", TWO_PASS.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=dict(base, **env))
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
