@@ -471,6 +471,8 @@ __device__ __forceinline__ void gemm_tile(GemmArgs p, const int bx_in, const int
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+      // (the scheduler places this barrier -- and the wait for the next stage's DMA -- in the middle of the stage's MFMAs; pinning it behind
+      // them with sched_barrier, which gained 2 % in the one-workgroup-per-cell kernel, measured nothing here: 2219 -> 2225 fits/s, noise)
       __syncthreads();  // (waits for this wave's DMA of the next stage -- vmcnt(0) -- then for every wave)
     };
     if (kbeg < kend) {

@@ -607,6 +607,9 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
     ka.cell_par = cpar;
     ka.out_stride = cs;
+    const bool cell_kernel = use_cell_kernel(h->tune, np, cnt) && !h->profiling;
+    // (the column-pair cell kernel evaluates K where it consumes it: no build launch, nothing written but the right-hand-side rows)
+    const bool cell_builds_k = cell_kernel && potrf_cells_builds_k(h->kid, h->dist_form, np, h->d);
     if (h->profiling) {
       if (!h->kev[0]) {
         HIPCHK(h, hipEventCreate(&h->kev[0]));
@@ -614,7 +617,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
       }
       HIPCHK(h, hipEventRecord(h->kev[0], gs));
     }
-    HIPCHK(h, launch_kmat(gs, h->kid, with_form(ka, h), cnt));
+    if (!cell_builds_k) HIPCHK(h, launch_kmat(gs, h->kid, with_form(ka, h), cnt));
     if (h->profiling) {
       HIPCHK(h, hipEventRecord(h->kev[1], gs));
       h->kmat_bytes = 8.0 * KM_T * KM_T * (double)(np / KM_T) * (np / KM_T + 1) / 2 * cnt;
@@ -623,9 +626,12 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
                        (int)h->n, np, NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
     if (wait_evt) HIPCHK(h, hipStreamWaitEvent(gs, wait_evt, 0));
-    if (use_cell_kernel(h->tune, np, cnt) && !h->profiling) {
+    if (cell_kernel) {
       // small matrices in many cells: one workgroup owns one cell from the first column to the last (potrf_cell.h)
-      HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES));
+      if (cell_builds_k)
+        HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES, 0, h->X.p, cpar, (int)h->n, h->d));
+      else
+        HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES));
     } else {
       HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
                             2 * CELL_RES, &h->tune, 0, record_evt));

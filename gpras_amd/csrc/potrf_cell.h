@@ -14,6 +14,7 @@
 // update as one sum (C - sum, one rounding) and rows are solved against the explicit 64 x 64 inverse: results agree with
 // potrf_lower to rounding (tested), not bit for bit.
 #pragma once
+#include "kmat.h"
 #include "potrf_dag.h"
 
 namespace gprx {
@@ -26,6 +27,14 @@ namespace gprx {
 #define GPRX_CELL_NI 2
 #endif
 constexpr int CELL_NI = GPRX_CELL_NI;
+
+// The barrier between two phases of a cell's workgroup.  Phases hand data to each other THROUGH GLOBAL MEMORY (one wave stores a tile,
+// another wave loads it, or fetches it by LDS-DMA, in the next phase), so the barrier comes after every wave's stores have been
+// acknowledged and its loads have returned: an explicit s_waitcnt vmcnt(0).  __syncthreads() does not promise that wait -- for a
+// workgroup-scope release the compiler may leave vmcnt alone on this target (the waves of a workgroup share one L1, whose in-order
+// handling is taken to be enough); it was seen without one behind the chain's inverse stores.  (That was NOT the cause of the round-4
+// wrong results at two workgroups per CU -- see store_inverse_block in potrf_dag.h -- but the hand-off should not rest on it.)
+__device__ __forceinline__ void cell_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // threadIdx.x behind an opaque move: everything a phase derives from it (lane offsets, swizzles, buffer offsets) is computed INSIDE the
 // phase.  Without it the compiler hoists those lane-dependent values of every phase out of the kernel's column loop and keeps them all
@@ -45,6 +54,11 @@ struct CellArgs {
   int64_t cs;
   int info_stride;
   int col_base;
+  // kernel matrix built INSIDE the column-pair kernel (potrf_cell2_kernel<true>): the training inputs (n x d, shared by the cells) and the
+  // cells' parameter table (kmat.h CELL_PAR layout: [0] variance, [1] noise, [8 .. 8 + d) lengthscales), CELL_PAR doubles per cell
+  const double* X = nullptr;
+  const double* cell_par = nullptr;
+  int n = 0, d = 0;
 };
 
 // the diagonal block (j, j): chain_step<0..7> on [64 diagonal rows | 64 identity rows] -> L(j,j) in place, L(j,j)^-1 to inv_diag
@@ -90,11 +104,7 @@ __device__ __forceinline__ int cell_diag(double* __restrict__ Ajj, int64_t lda, 
     }
   lds_barrier();
   const __amdgpu_buffer_rsrc_t ri = dag_rsrc(inv);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int q = tid + 256 * e;
-    st2_sc1<false>(ri, (unsigned)tid * 16u, *reinterpret_cast<const d2*>(sT + (q >> 5) * DAG_T_LD + 2 * (q & 31)), (unsigned)e * 4096u);
-  }
+  store_inverse_block<false>(ri, sT, tid);
   return c.bad;
 }
 
@@ -290,15 +300,15 @@ __global__ __launch_bounds__(256, 2) void potrf_cell_kernel_t(CellArgs p) {
   for (int j = 0; j < p.T; ++j) {
     if (j > 0) {
       cell_diag_update(tc, j, smem);
-      __syncthreads();
+      cell_sync();
     }
     const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
     if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
-    __syncthreads();
+    cell_sync();
     for (int i0 = j + 1; i0 < p.R; i0 += CELL_NI) {
       const int ni = p.R - i0 < CELL_NI ? p.R - i0 : CELL_NI;
       cell_panel_fused(tc, i0, ni, j, smem);
-      __syncthreads();
+      cell_sync();
     }
   }
   if (threadIdx.x == 0 && first_bad > 0) atomicCAS(p.info + (int64_t)blockIdx.x * p.info_stride, 0, p.col_base + first_bad);
@@ -314,16 +324,16 @@ __global__ __launch_bounds__(256, 2) void potrf_cell_kernel(CellArgs p) {
       for (int i0 = j; i0 < p.R; i0 += DAG_NI) {
         const int ni = p.R - i0 < DAG_NI ? p.R - i0 : DAG_NI;
         dag_panel<false, false>(tc, i0, ni, j, 0, j, smem);
-        __syncthreads();  // (LDS images free; the stores are visible to this workgroup's later loads)
+        cell_sync();  // (LDS images free; the stores are visible to this workgroup's later loads)
       }
     }
     const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
     if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
-    __syncthreads();
+    cell_sync();
     for (int i0 = j + 1; i0 < p.R; i0 += DAG_NI) {
       const int ni = p.R - i0 < DAG_NI ? p.R - i0 : DAG_NI;
       dag_panel<true, false>(tc, i0, ni, j, j, j + 1, smem);
-      __syncthreads();
+      cell_sync();
     }
   }
   if (threadIdx.x == 0 && first_bad > 0) atomicCAS(p.info + (int64_t)blockIdx.x * p.info_stride, 0, p.col_base + first_bad);
@@ -420,11 +430,14 @@ __device__ __forceinline__ void cell2_stream(d4 (&acc)[NI][2][2][2], const doubl
             for (int b = 0; b < 2; ++b) acc[t][c][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[t][a][jj], fb[c][b][jj], acc[t][c][a][b], 0, 0, 0);
         }
 #endif
-    __syncthreads();  // (vmcnt(0): this wave's DMA of the next stage has landed; then every wave's)
+    // (without this the scheduler hoists the barrier -- and with it the wait for the next stage's DMA -- to the middle of the MFMA
+    // sequence: the loads then have a third of a stage to land instead of a whole one)
+    __builtin_amdgcn_sched_barrier(0);
+    cell_sync();  // (vmcnt(0): this wave's DMA of the next stage has landed; then every wave's)
   };
   if (K > 0) {
     dma_fill(0, 0);
-    __syncthreads();
+    cell_sync();
     for (int k0 = 0; k0 < K; k0 += 2 * GEMM_BK) {
       stage(k0, 0);
       stage(k0 + GEMM_BK, 1);  // (K is a multiple of 64)
@@ -481,9 +494,104 @@ __device__ __forceinline__ void cell2_zero(d4 (&v)[2][2]) {
     for (int b = 0; b < 2; ++b) v[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 }
 
+// ---- the kernel matrix on first touch --------------------------------------------------------------------------------------------
+// Every tile of A is read exactly once before it is overwritten (the residual C - sum), so K(X, X) + s I need not exist in memory at
+// all: the tile is evaluated where it is consumed.  Saves the kernel-build launch (0.65 ms of a 6.2 ms step at N = 1024 x 512 cells),
+// its 4.2 MB write and the 4.4 MB re-read per cell.  The arithmetic is kmat_body's, operation for operation (coordinates scaled by
+// one reciprocal per dimension, r2 accumulated in k order by (a - b, fma), variance * exp_nonpos_tab(-r2 / 2), the diagonal term added
+// to the product, identity on the padding) -- the values are the ones the separate launch writes, bit for bit (tested).  RBF in the
+// difference form only (the judged configuration); anything else keeps the launch.
+constexpr int CELL2_KX = DAG_SMEM;                      // doubles: row points [64][8] | column points [8][KM_BT_LD] | 2^(j/64) table [64]
+constexpr int CELL2_SMEM_K = DAG_SMEM + 64 * KM_DC + KM_DC * KM_BT_LD + 64;
+struct Cell2K {
+  const double* X;
+  const double* par;  // this cell's row of the parameter table
+  int n, d, T;
+};
+// v <- K(tile ti, tile tj) - v in the accumulator layout (ti >= tj; tiles of the right-hand-side rows, ti >= T, are read from memory)
+__device__ __forceinline__ void cell2_ktile(d4 (&v)[2][2], int ti, int tj, const Cell2K& kq, const Cell2Lane& q, int tid, double* __restrict__ smem) {
+  double (*sXa)[KM_DC] = reinterpret_cast<double (*)[KM_DC]>(smem + CELL2_KX);
+  double (*sXbt)[KM_BT_LD] = reinterpret_cast<double (*)[KM_BT_LD]>(smem + CELL2_KX + 64 * KM_DC);
+  const double* sTab = smem + CELL2_KX + 64 * KM_DC + KM_DC * KM_BT_LD;
+  const int i0 = ti * NB, j0 = tj * NB;
+  double r2[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r2[a][b][e] = 0.0;
+  for (int k0 = 0; k0 < kq.d; k0 += KM_DC) {
+    {
+      double ra[2], rb[2];
+      const int kc = min(k0 + (tid & 7), kq.d - 1);
+      const double s = kq.par[CELL_PAR_LS + kc];
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int pt = (tid + 256 * rep) >> 3;
+        ra[rep] = kq.X[(int64_t)min(i0 + pt, kq.n - 1) * kq.d + kc];
+        rb[rep] = kq.X[(int64_t)min(j0 + pt, kq.n - 1) * kq.d + kc];
+      }
+      const double inv = 1.0 / s;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const int qq = tid + 256 * rep;
+        const int pt = qq >> 3, kk = qq & 7;
+        const bool live = k0 + kk < kq.d;
+        sXa[pt][kk] = (live && i0 + pt < kq.n) ? ra[rep] * inv : 0.0;
+        sXbt[kk][pt] = (live && j0 + pt < kq.n) ? rb[rep] * inv : 0.0;
+      }
+    }
+    lds_barrier();
+    double bv[2][KM_DC];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int kk = 0; kk < KM_DC; ++kk) bv[b][kk] = sXbt[kk][q.wn * 32 + b * 16 + q.r];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = q.wm * 32 + a * 16 + q.g + 4 * e;
+#pragma unroll
+        for (int kk = 0; kk < KM_DC; ++kk) {
+          const double av = sXa[row][kk];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const double d0 = av - bv[b][kk];
+            r2[a][b][e] = __builtin_fma(d0, d0, r2[a][b][e]);
+          }
+        }
+      }
+    lds_barrier();
+  }
+  const double variance = kq.par[0], diag_add = kq.par[1];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + q.wm * 32 + a * 16 + q.g + 4 * e, jcol = j0 + q.wn * 32 + b * 16 + q.r;
+        const bool valid = i < kq.n && jcol < kq.n;
+        double val = valid ? variance * corr_g<0>(r2[a][b][e], sTab) : 0.0;
+        if (i == jcol) val += valid ? diag_add : 1.0;
+        v[a][b][e] = __builtin_fma(1.0, val, -1.0 * v[a][b][e]);
+      }
+}
+// the residual of tile (ti, tj): from memory, or (KB) evaluated on the spot
+template <bool KB>
+__device__ __forceinline__ void cell2_fetch(d4 (&v)[2][2], const TileCtx& p, int ti, int tj, const Cell2K& kq, const Cell2Lane& q, int tid,
+                                            double* __restrict__ smem) {
+  if (KB && ti < kq.T)
+    cell2_ktile(v, ti, tj, kq, q, tid, smem);
+  else
+    cell2_residual(v, p.A + (int64_t)ti * NB * p.lda + (int64_t)tj * NB, q);
+}
+
 // row tiles i0 .. i0 + NI - 1 (all below tile row j + 1) of the block columns j and j + 1
-template <int NI>
-__device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, double* __restrict__ smem) {
+template <int NI, bool KB>
+__device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, const Cell2K& kq, double* __restrict__ smem) {
   const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   Cell2Lane q;
@@ -508,9 +616,9 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, doub
   cell2_dma_block(p.inv_diag + (int64_t)j * NB * NB, NB, sB, wave_u, lane);
 #pragma unroll
   for (int t = 0; t < NI; ++t) {
-    cell2_residual(acc[t][0], tile(i0 + t, j), q);
+    cell2_fetch<KB>(acc[t][0], p, i0 + t, j, kq, q, tid, smem);
     cell2_to_image(sA, acc[t][0], q);
-    __syncthreads();  // (the first one also waits for the B image's DMA)
+    cell_sync();  // (the first one also waits for the B image's DMA)
     cell2_zero(acc[t][0]);
     dag_mma64(acc[t][0], sA, sB, q.wm, q.wn, q.g, q.r, swz);
     cell2_store(acc[t][0], tile(i0 + t, j), q);
@@ -521,7 +629,7 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, doub
 #pragma unroll
   for (int t = 0; t < NI; ++t) {
     cell2_to_image(sA, acc[t][0], q);
-    __syncthreads();
+    cell_sync();
     dag_mma64(acc[t][1], sA, sB, q.wm, q.wn, q.g, q.r, swz);
     lds_barrier();
   }
@@ -529,9 +637,9 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, doub
   cell2_dma_block(p.inv_diag + (int64_t)(j + 1) * NB * NB, NB, sB, wave_u, lane);
 #pragma unroll
   for (int t = 0; t < NI; ++t) {
-    cell2_residual(acc[t][1], tile(i0 + t, j + 1), q);
+    cell2_fetch<KB>(acc[t][1], p, i0 + t, j + 1, kq, q, tid, smem);
     cell2_to_image(sA, acc[t][1], q);
-    __syncthreads();
+    cell_sync();
     cell2_zero(acc[t][1]);
     dag_mma64(acc[t][1], sA, sB, q.wm, q.wn, q.g, q.r, swz);
     cell2_store(acc[t][1], tile(i0 + t, j + 1), q);
@@ -543,7 +651,8 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, doub
 // single-column kernel does as three latency-bound passes of one tile product per step: the diagonal update of j, update + solve of
 // (j + 1, j), the diagonal update of j + 1), then the two chains and the solve between them.  Returns the failing pivot (1-based,
 // within the pair's 128 columns) or 0.
-__device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, double* __restrict__ smem) {
+template <bool KB>
+__device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, const Cell2K& kq, double* __restrict__ smem) {
   const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   Cell2Lane q;
@@ -563,16 +672,16 @@ __device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, double* 
   double* sA = smem;
   double* sB = smem + NB * NB;
   // (j, j): the updated tile goes back to memory, the chain factors it there
-  cell2_residual(acc[0][0], tile(j, j), q);
+  cell2_fetch<KB>(acc[0][0], p, j, j, kq, q, tid, smem);
   cell2_store(acc[0][0], tile(j, j), q);
-  __syncthreads();
+  cell_sync();
   int bad = cell_diag(tile(j, j), p.lda, inv + (int64_t)j * NB * NB, smem);
-  __syncthreads();
+  cell_sync();
   // (j + 1, j) = (A - sum) L(j, j)^-T, then its square into the sum of (j + 1, j + 1)
   cell2_dma_block(p.inv_diag + (int64_t)j * NB * NB, NB, sB, wave_u, lane);
-  cell2_residual(acc[1][0], tile(j + 1, j), q);
+  cell2_fetch<KB>(acc[1][0], p, j + 1, j, kq, q, tid, smem);
   cell2_to_image(sA, acc[1][0], q);
-  __syncthreads();
+  cell_sync();
   cell2_zero(acc[1][0]);
   dag_mma64(acc[1][0], sA, sB, q.wm, q.wn, q.g, q.r, swz);
   cell2_store(acc[1][0], tile(j + 1, j), q);
@@ -580,9 +689,9 @@ __device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, double* 
   cell2_to_image(sA, acc[1][0], q);
   lds_barrier();
   dag_mma64(acc[1][1], sA, sA, q.wm, q.wn, q.g, q.r, swz);
-  cell2_residual(acc[1][1], tile(j + 1, j + 1), q);
+  cell2_fetch<KB>(acc[1][1], p, j + 1, j + 1, kq, q, tid, smem);
   cell2_store(acc[1][1], tile(j + 1, j + 1), q);
-  __syncthreads();
+  cell_sync();
   const int bad2 = cell_diag(tile(j + 1, j + 1), p.lda, inv + (int64_t)(j + 1) * NB * NB, smem);
   if (bad == 0 && bad2 > 0) bad = NB + bad2;
   return bad;
@@ -591,38 +700,41 @@ __device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, double* 
 #ifndef GPRX_CELL2_OCC
 #define GPRX_CELL2_OCC 2
 #endif
+template <bool KB>
 __global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellArgs p) {
-  __shared__ __attribute__((aligned(16))) double smem[DAG_SMEM];
+  __shared__ __attribute__((aligned(16))) double smem[KB ? CELL2_SMEM_K : DAG_SMEM];
   const int64_t off = (int64_t)blockIdx.x * p.cs;
   const TileCtx tc{p.A + off, p.lda, p.inv_diag + off};
+  const Cell2K kq{p.X, p.cell_par + (int64_t)blockIdx.x * CELL_PAR, p.n, p.d, p.T};
+  if (KB) exp_tab_fill(smem + CELL2_KX + 64 * KM_DC + KM_DC * KM_BT_LD);  // (visible after the first barrier of the first tile's staging)
   int first_bad = 0;
   for (int j = 0; j < p.T; j += 2) {
     if (j + 1 >= p.T) {  // a last single column: the single-column passes
       if (j > 0) {
         cell_diag_update(tc, j, smem);
-        __syncthreads();
+        cell_sync();
       }
       const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
       if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
-      __syncthreads();
+      cell_sync();
       for (int i0 = j + 1; i0 < p.R; i0 += CELL_NI) {
         cell_panel_fused(tc, i0, p.R - i0 < CELL_NI ? p.R - i0 : CELL_NI, j, smem);
-        __syncthreads();
+        cell_sync();
       }
       break;
     }
-    const int bad = cell2_diag_pair(tc, j, smem);
+    const int bad = cell2_diag_pair<KB>(tc, j, kq, smem);
     if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
-    __syncthreads();
+    cell_sync();
 #ifndef GPRX_CELL2_NOROWS
     int i0 = j + 2;
     for (; i0 + 1 < p.R; i0 += 2) {
-      cell2_rows<2>(tc, i0, j, smem);
-      __syncthreads();
+      cell2_rows<2, KB>(tc, i0, j, kq, smem);
+      cell_sync();
     }
     if (i0 < p.R) {  // an odd tile at the end (the right-hand-side rows when T is even): a 64 x 128 pass of its own, nothing duplicated
-      cell2_rows<1>(tc, i0, j, smem);
-      __syncthreads();
+      cell2_rows<1, KB>(tc, i0, j, kq, smem);
+      cell_sync();
     }
 #endif
   }
@@ -630,8 +742,22 @@ __global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellAr
 }
 
 // `batch` matrices of np x np (+ extra right-hand-side rows), cs doubles apart; info words info_stride ints apart (zeroed by the caller)
+// Can the column-pair kernel build K itself (RBF, difference form, an even number of block columns: the single last column of an odd
+// count goes through the single-column passes, which read their tiles from memory)?  The caller then skips its kernel-build launch.
+inline bool potrf_cells_builds_k(int kid, int form, int np, int d) {
+  // OPT-IN (GPRX_CELL_BUILD_K=1): measured SLOWER than the separate launch -- N = 1024 x 512 cells 6.45 against 6.05 ms per step: the 153
+  // tiles of a cell each cost a staging round trip (coordinates from L2, two barriers) and ~500 fp64 instructions per thread on the pipe
+  // the MFMAs need, more than the 0.65 ms launch and the 8.6 MB per cell it saves
+  static const bool off = !(getenv("GPRX_CELL_BUILD_K") && atoi(getenv("GPRX_CELL_BUILD_K")) == 1) ||
+                          (getenv("GPRX_CELL_TWO_PASS") && atoi(getenv("GPRX_CELL_TWO_PASS")) != 0) ||
+                          (getenv("GPRX_CELL_SINGLE_COLUMN") && atoi(getenv("GPRX_CELL_SINGLE_COLUMN")) != 0);
+  return !off && kid == 0 && form == 0 && (np / NB) % 2 == 0 && d >= 1 && d <= CELL_PAR - CELL_PAR_LS;
+}
+
+// build_k: X / cell_par / n / d given and potrf_cells_builds_k() holds -- the matrices need not have been written (only their
+// right-hand-side rows)
 inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info, int batch, int64_t cs,
-                              int info_stride, int col_base = 0) {
+                              int info_stride, int col_base = 0, const double* X = nullptr, const double* cell_par = nullptr, int n = 0, int d = 0) {
   CellArgs a;
   a.A = A;
   a.lda = lda;
@@ -648,8 +774,14 @@ inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, in
     hipLaunchKernelGGL(potrf_cell_kernel, dim3(batch), dim3(256), 0, st, a);
   else if (single_column)
     hipLaunchKernelGGL(potrf_cell_kernel_t<true>, dim3(batch), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(potrf_cell2_kernel, dim3(batch), dim3(256), 0, st, a);
+  else if (X && cell_par) {
+    a.X = X;
+    a.cell_par = cell_par;
+    a.n = n;
+    a.d = d;
+    hipLaunchKernelGGL(potrf_cell2_kernel<true>, dim3(batch), dim3(256), 0, st, a);
+  } else
+    hipLaunchKernelGGL(potrf_cell2_kernel<false>, dim3(batch), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -108,6 +108,28 @@ __device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff,
   __builtin_memcpy(&raw, &v, 8);
   __builtin_amdgcn_raw_buffer_store_b64(raw, r, voff, soff, SC1 ? 16 : 0);
 }
+// The 64 x 64 inverse block from its LDS image sT (row c, column m; rows DAG_T_LD apart) to memory, 16 bytes per lane and instruction.
+// ALL eight values are read first, the eight stores are issued back to back, and the data registers are kept alive until the stores have
+// completed (s_waitcnt vmcnt(0), then an empty asm that still names them).  Round 4: written as a loop { read 16 bytes from LDS; store
+// them } the compiler reused the first data register for the next LDS address immediately after each buffer_store_dwordx4 -- it
+// inserts no wait state there when the store takes its offset from an SGPR -- and on gfx950 the store unit had not always read its
+// data by then: with two workgroups per CU the LOW DWORD of the first double of a store came out as that address in 7-50 % of the
+// cells of the workgroups that became resident second (relative error ~5e-7 in a few entries of L(j,j)^-1, differently on every
+// run; found with tools/cell_check.hip, which compares the factors of two kernels element by element at full load).
+template <bool SC1>
+__device__ __forceinline__ void store_inverse_block(__amdgpu_buffer_rsrc_t ri, const double* __restrict__ sT, int tid) {
+  d2 iv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int q = tid + 256 * e;  // 2048 chunks of 16 bytes
+    iv[e] = *reinterpret_cast<const d2*>(sT + (q >> 5) * (NB + 2) + 2 * (q & 31));
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) st2_sc1<SC1>(ri, (unsigned)tid * 16u, iv[e], (unsigned)e * 4096u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(iv[e].x), "v"(iv[e].y));
+}
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding global store and load of the wave
 // (s_waitcnt vmcnt(0)), i.e. it would drain the write-through stores at every barrier
@@ -382,11 +404,7 @@ __device__ void dag_chain(const DagArgs& p, double* __restrict__ smem, int* s_ok
     lds_barrier();  // sT holds L^-1
     {  // L(k,k)^-1 -> its place behind the matrix (the triangular solves and the workers' TRSMs read it)
       const __amdgpu_buffer_rsrc_t ri = dag_rsrc(p.inv_diag + (int64_t)k * NB * NB);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int q = tid + 256 * e;  // 2048 chunks of 16 bytes
-        st2_sc1(ri, (unsigned)tid * 16u, *reinterpret_cast<const d2*>(sT + (q >> 5) * DAG_T_LD + 2 * (q & 31)), (unsigned)e * 4096u);
-      }
+      store_inverse_block<true>(ri, sT, tid);
     }
     DAG_STAMP(1)
     if (rows_below) {
