@@ -2969,6 +2969,9 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
   else if (k == "dag" && value >= -1 && value <= 1) t.dag = value;
+  else if (k == "rows_inv" && value >= -1 && value <= 1) t.rows_inv = value;
+  else if (k == "rows_inv_rt" && value >= 0 && value <= 2) t.rows_inv_rt = value;
+  else if (k == "rows_inv_lone" && value >= 0 && value <= 1) t.rows_inv_lone = value;
   else if (k == "cell_kernel" && value >= -1 && value <= 1) t.cell_kernel = value;
   else if (k == "split_updates" && value >= 0 && value <= 1) t.split_updates = value;
   else if (k == "poison_workspace" && value >= 0 && value <= 1) t.poison_workspace = value;

@@ -609,6 +609,132 @@ __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict
     }
 }
 
+// ---- split panel, rows by ONE tile product against the diagonal block's inverse (round 4) ----------------------------------
+// X = A21 L11^-T with the explicit L11^-1 that the diagonal workgroup leaves in inv_diag anyway (row-major, exact zeros above
+// the diagonal): per 16-row tile 40 MFMAs (the k range of output tile column kt ends at 16 kt + 15) and NO fp64 vector chain --
+// potrf_rows_kernel's 8 x (LDS round trip, 44-FMA substitution, MFMA update) is what runs 1.7-2.3x slower beside a bulk update,
+// because fp64 vector and matrix instructions share one pipe on gfx950; this kernel is loads -> MFMA -> stores.
+// Operands come straight from global memory in MFMA operand layout (lane (g, r): row r of the tile, 4 consecutive k = 32 bytes,
+// the four lane groups of a row = one 128-byte line); the 32 KB inverse is L1/L2 resident.  Results equal the substitution's to
+// rounding (||L11^-1|| eps instead of the substitution's backward-stable rows), not bit for bit: include/gprx.h says where.
+// FUSE_K64: as potrf_rows_kernel -- the K = 64 update by the 64 columns left of these is applied on the way in (same operation
+// order as the separate launch, so fused == unfused bit for bit); the updated rows pass through a wave-private LDS image
+// (accumulator layout -> operand layout), 16 rows at a time.
+constexpr int RINV_LD = NB;  // doubles per row of the wave-private transposition image: 4 x 16 x 64 doubles = 32 KB per workgroup (the
+                             // slot a capped bulk update leaves free on a CU); 32-byte groups XOR-ed with the row against bank conflicts
+template <int RT, int OCC, bool FUSE_K64 = false>
+__global__ __launch_bounds__(256, OCC) void potrf_rows_inv_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
+                                                                  const double* __restrict__ inv, int64_t cs) {
+  constexpr int WG_ROWS = 64 * RT, WROWS = 16 * RT;
+  __shared__ __attribute__((aligned(16))) double sT[FUSE_K64 ? 4 * 16 * RINV_LD : 2];
+  A21 += (int64_t)blockIdx.y * cs;
+  inv += (int64_t)blockIdx.y * cs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  const int row0 = blockIdx.x * WG_ROWS + WROWS * wave;
+  double fa[RT][4][4];  // [tile][stage of 16 along k][instruction]: A operand of instruction j of stage s = A[row r][16 s + 4 g + j]
+  if constexpr (!FUSE_K64) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int idx = row0 + 16 * rt + r;
+      const double* p = A21 + (int64_t)(idx < rows_below ? idx : 0) * lda + 4 * g;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const d2 lo = *reinterpret_cast<const d2*>(p + 16 * s), hi = *reinterpret_cast<const d2*>(p + 16 * s + 2);
+        fa[rt][s][0] = lo.x; fa[rt][s][1] = lo.y; fa[rt][s][2] = hi.x; fa[rt][s][3] = hi.y;
+      }
+    }
+  } else {
+    // the K = 64 update exactly as potrf_rows_kernel<..., FUSE_K64> applies it (accumulators from zero, stages of 16, C - sum)
+    d4 upd[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) upd[rt][kt] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* arow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int idx = row0 + 16 * rt + r;
+      arow[rt] = A21 + (int64_t)(idx < rows_below ? idx : 0) * lda - NB + 4 * g;
+    }
+    const double* brow = A21 - (int64_t)NB * lda + (int64_t)r * lda - NB + 4 * g;
+#pragma unroll
+    for (int k0 = 0; k0 < NB; k0 += 16) {
+      double ua[RT][4], ub[4][4];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const d2 lo = *reinterpret_cast<const d2*>(arow[rt] + k0), hi = *reinterpret_cast<const d2*>(arow[rt] + k0 + 2);
+        ua[rt][0] = lo.x; ua[rt][1] = lo.y; ua[rt][2] = hi.x; ua[rt][3] = hi.y;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const double* bp = brow + (int64_t)(16 * kt) * lda + k0;
+        const d2 lo = *reinterpret_cast<const d2*>(bp), hi = *reinterpret_cast<const d2*>(bp + 2);
+        ub[kt][0] = lo.x; ub[kt][1] = lo.y; ub[kt][2] = hi.x; ub[kt][3] = hi.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) upd[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[rt][j], ub[kt][j], upd[rt][kt], 0, 0, 0);
+    }
+    double* img = sT + wave * 16 * RINV_LD;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (rt) wave_sync_lds();  // (the image is reused: the previous tile's reads are done)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = row0 + 16 * rt + g + 4 * q;
+        const double* src = A21 + (int64_t)(idx < rows_below ? idx : 0) * lda + r;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const double v = -1.0 * upd[rt][kt][q];
+          img[(g + 4 * q) * RINV_LD + 4 * (((4 * kt + (r >> 2)) ^ (g + 4 * q)) & 15) + (r & 3)] = __builtin_fma(1.0, src[kt * 16], v);
+        }
+      }
+      wave_sync_lds();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double* gp = img + r * RINV_LD + 4 * (((4 * s + g) ^ r) & 15);
+        const d2 lo = *reinterpret_cast<const d2*>(gp), hi = *reinterpret_cast<const d2*>(gp + 2);
+        fa[rt][s][0] = lo.x; fa[rt][s][1] = lo.y; fa[rt][s][2] = hi.x; fa[rt][s][3] = hi.y;
+      }
+    }
+  }
+  d4 acc[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc[rt][kt] = d4{0.0, 0.0, 0.0, 0.0};
+  const double* bp = inv + r * NB + 4 * g;  // B operand: (L11^-T)[k][c] = L11^-1[c][k], c = 16 kt + r, k = 16 s + 4 g + j
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double fb[4][4];
+#pragma unroll
+    for (int kt = s; kt < 4; ++kt) {
+      const d2 lo = *reinterpret_cast<const d2*>(bp + 16 * kt * NB + 16 * s), hi = *reinterpret_cast<const d2*>(bp + 16 * kt * NB + 16 * s + 2);
+      fb[kt][0] = lo.x; fb[kt][1] = lo.y; fb[kt][2] = hi.x; fb[kt][3] = hi.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int kt = s; kt < 4; ++kt) acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][s][j], fb[kt][j], acc[rt][kt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = row0 + 16 * rt + g + 4 * q;
+      if (idx < rows_below) {
+        double* dst = A21 + (int64_t)idx * lda + r;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) dst[kt * 16] = acc[rt][kt][q];
+      }
+    }
+}
+
 // ---- 128-column panel: the same algorithm with a 128 x 128 diagonal block ------------------------
 // Workgroup rows 0..127 = the diagonal block, rows 128..255 = 128 rows of A21 (last workgroup: 128
 // identity rows).  Wave w owns workgroup rows 64 w .. 64 w + 63: acc[4][8] = 64 rows x 128 columns.
@@ -1044,6 +1170,9 @@ struct PotrfTuning {
   int split_updates = 0; // lone matrix: 1 = look-ahead split of the K >= 256 updates over a side stream (see potrf_lower; measured
                          // slower: 2.17 -> 2.66 ms at N = 4096), 0 = every update whole on the main stream (default)
   int cell_kernel = 0;   // batched cells: 1 = always one workgroup per cell (potrf_cell.h), -1 never, 0 = for np <= 1024 and >= 256 cells
+  int rows_inv = 0;      // split panel: 1 = rows below the diagonal block by one MFMA tile product against L11^-1 (potrf_rows_inv_kernel), 0 / -1 = substitution
+  int rows_inv_rt = 0;   // 16-row tiles per wave of that kernel: 1 (default) or 2
+  int rows_inv_lone = 0; // 1 = a lone matrix takes the split panel + rows_inv too (experiments at N >= 8192)
   int dag = 0;           // lone matrices: 1 = the tile-DAG factorisation (potrf_dag.h); 0 / -1 = the launch-per-panel schedule (default)
 };
 inline PotrfTuning& potrf_tuning() {
@@ -1057,6 +1186,9 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
     if (const char* e = getenv("GPRX_SPLIT_PANEL")) v.split_panel = atoi(e);
     if (const char* e = getenv("GPRX_DAG")) v.dag = atoi(e);
+    if (const char* e = getenv("GPRX_ROWS_INV")) v.rows_inv = atoi(e);
+    if (const char* e = getenv("GPRX_ROWS_INV_RT")) v.rows_inv_rt = atoi(e);
+    if (const char* e = getenv("GPRX_ROWS_INV_LONE")) v.rows_inv_lone = atoi(e);
     if (const char* e = getenv("GPRX_SPLIT_UPDATES")) v.split_updates = atoi(e);
     if (const char* e = getenv("GPRX_CELL_KERNEL")) v.cell_kernel = atoi(e);
     return v;
@@ -1156,7 +1288,9 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
   hipError_t err = hipSuccess;
   // split panel (diagonal workgroup, then a rows-only kernel): pays one more dependent launch per panel and wins once
   // a fused launch would fill the chip with redundant factorisations; bit-identical either way
-  const bool split_panel = tune.split_panel ? tune.split_panel > 0 : batch >= 24;  // measured at N = 4096: -2 % at 16 cells per launch, +5 % at 32
+  const bool rows_inv = tune.rows_inv > 0;  // split panel: rows by one tile product against L11^-1 (potrf_rows_inv_kernel) instead of the substitution
+  const int rows_inv_rt = tune.rows_inv_rt == 2 ? 2 : 1;  // 16-row tiles per wave of that kernel (64 or 128 rows per workgroup)
+  const bool split_panel = tune.split_panel ? tune.split_panel > 0 : (batch >= 24 || (rows_inv && tune.rows_inv_lone > 0));  // measured at N = 4096: -2 % at 16 cells per launch, +5 % at 32
   // one panel: factor the diagonal block at column c and solve every row below it
   // fuse: the K = 64 update of these 64 columns by the 64 columns left of them happens inside the panel kernel (lone
   // matrices: one dependent launch less); only where the separate launch would be the general NT kernel (same arithmetic)
@@ -1239,7 +1373,16 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
         // workgroup barriers become wave-scope fences (another -0.3 ms).  GPRX_ROWS_LDS=1 restores the LDS image and the barriers
         // (same values either way).
         static const bool rows_lds = getenv("GPRX_ROWS_LDS") != nullptr;
-        if (fuse)
+        const dim3 grid_inv((rows_below + 64 * rows_inv_rt - 1) / (64 * rows_inv_rt), batch);
+        if (rows_inv && rows_inv_rt == 1 && fuse)
+          hipLaunchKernelGGL((potrf_rows_inv_kernel<1, 4, true>), grid_inv, dim3(256), 0, st, Acc + (int64_t)NB * lda, lda, rows_below, (const double*)invd, cs);
+        else if (rows_inv && rows_inv_rt == 1)
+          hipLaunchKernelGGL((potrf_rows_inv_kernel<1, 4>), grid_inv, dim3(256), 0, st, Acc + (int64_t)NB * lda, lda, rows_below, (const double*)invd, cs);
+        else if (rows_inv && fuse)
+          hipLaunchKernelGGL((potrf_rows_inv_kernel<2, 2, true>), grid_inv, dim3(256), 0, st, Acc + (int64_t)NB * lda, lda, rows_below, (const double*)invd, cs);
+        else if (rows_inv)
+          hipLaunchKernelGGL((potrf_rows_inv_kernel<2, 2>), grid_inv, dim3(256), 0, st, Acc + (int64_t)NB * lda, lda, rows_below, (const double*)invd, cs);
+        else if (fuse)
           hipLaunchKernelGGL((potrf_rows_kernel<2, 2, true, true, true, true>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
                              Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs);
         else if (rows_lds)

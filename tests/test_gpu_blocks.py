@@ -256,6 +256,42 @@ def test_split_panel_is_bit_identical_to_the_fused_panel(lib):
         assert rel_err(a, b) < 1e-13
 
 
+@pytest.mark.parametrize("n,extra,rt", [(128, 0, 1), (1024, 64, 1), (1088, 40, 2), (2048, 64, 2), (2048 + 192, 17, 1)])
+def test_rows_by_inverse_product_equals_the_substitution_to_rounding(lib, n, extra, rt):
+    """potrf_rows_inv_kernel (split panel, rows = A21 L11^-T as one MFMA tile product against the diagonal block's inverse,
+    "rows_inv" = 1): against scipy and against the substitution schedule -- equal to rounding, not bit for bit -- for both
+    tile counts per wave, the fused K = 64 update (odd panels) and ragged row counts; repeated runs are bit-identical."""
+    rng = np.random.default_rng(n + rt)
+    g = rng.standard_normal((n, 80))
+    spd = g @ g.T / 80 + np.eye(n)
+    rhs = rng.standard_normal((extra, n))
+    full = np.vstack([spd, rhs]) if extra else spd
+    L_ref = cholesky(spd, lower=True)
+    outs = []
+    try:
+        for inv in (0, 1, 1):
+            check(lib.gprx_set_tuning(b"split_panel", 1))
+            check(lib.gprx_set_tuning(b"rows_inv", inv))
+            check(lib.gprx_set_tuning(b"rows_inv_rt", rt))
+            dA, dI = DeviceBuffer.from_array(full), DeviceBuffer(n * 64 * 8)
+            info = C.c_int(0)
+            check(lib.gprx_potrf(0, dA.ptr, n, n, extra, dI.ptr, C.byref(info)))
+            assert info.value == 0
+            outs.append(dA.to_array((n + extra, n)))
+            dA.free()
+            dI.free()
+    finally:
+        for key in (b"split_panel", b"rows_inv", b"rows_inv_rt"):
+            lib.gprx_set_tuning(key, 0)
+    for out in outs:
+        assert rel_err(np.tril(out[:n]), L_ref) < 1e-11
+        if extra:
+            assert rel_err(out[n:], solve_triangular(L_ref, rhs.T, lower=True).T) < 1e-11
+    assert rel_err(np.tril(outs[1][:n]), np.tril(outs[0][:n])) < 1e-13
+    assert not np.array_equal(np.tril(outs[1][:n]), np.tril(outs[0][:n]))  # (it IS another arithmetic: the knob reached the kernel)
+    assert np.array_equal(outs[1], outs[2])
+
+
 @pytest.mark.parametrize("n,extra,ni", [(64, 64, 4), (192, 0, 4), (2048, 64, 4), (3136, 0, 2), (2112, 128, 1), (4096, 64, 4)])
 def test_potrf_tile_dag(lib, n, extra, ni, monkeypatch):
     """The tile-DAG factorisation of a lone matrix (potrf_dag.h: one persistent launch, chain workgroup + task-queue workers,
