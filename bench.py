@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 
 
 MAIN_KERNEL = "gemm_f64_kernel<0,1,64,64,0,0,1>"
-PMC_FILE = "r03_pmc_hbm_traffic.json"
+PMC_FILE = "r04_pmc_hbm_traffic.json"
 
 
 def pmc_traffic(kernel):
@@ -643,9 +643,40 @@ def main():
                         "panel_launches": pr[4], "panel_avg_launch_us": 1e3 * pr[3] / max(pr[4], 1.0),
                         "short_k_launches": pr[6], "short_k_tflops": (pr[7] / (pr[5] * 1e-3) / 1e12) if pr[5] > 0 else None}
 
-            sizes["N1024_d8_roofline"] = roofline_block(
+            # the kernel that IS the default at this size: ONE launch of the one-workgroup-per-cell Cholesky (potrf_cell2_kernel), timed by HIP
+            # events around that launch on its stream (gprx_last_cell_kernel; the handle forces the kernel so that the profiled pass runs it)
+            check(lib.gprx_set_handle_tuning(h1, b"cell_kernel", 1), h1)
+            check(lib.gprx_set_profiling(h1, 1), h1)
+            cms, cfl, ccells, best_c = C.c_double(), C.c_double(), C.c_double(), None
+            try:
+                for _ in range(3):
+                    check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1)
+                    check(lib.gprx_last_cell_kernel(h1, C.byref(cms), C.byref(cfl), C.byref(ccells)), h1)
+                    if cms.value > 0 and (best_c is None or cms.value < best_c[0]):
+                        best_c = (cms.value, cfl.value, ccells.value)
+            finally:
+                check(lib.gprx_set_profiling(h1, 0), h1)
+                check(lib.gprx_set_handle_tuning(h1, b"cell_kernel", 0), h1)
+            if best_c:
+                ach = best_c[1] / (best_c[0] * 1e-3) / 1e12
+                # HBM bytes per launch from the committed PMC passes over this kernel (separate FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH + WRITE)
+                traffic = None
+                try:
+                    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_cell_kernel.json")) as f:
+                        traffic = float(json.load(f)["kernels"]["potrf_cell2_kernel<false>"]["hbm_bytes_per_launch_corrected"])
+                except Exception:  # noqa: BLE001
+                    pass
+                sizes["N1024_d8_roofline"] = {
+                    "kernel": "gprx::potrf_cell2_kernel<false>: the whole Cholesky of 512 cells of N = 1024 (+ 64 right-hand-side rows) in ONE launch, one workgroup per cell (column pairs, LDS-DMA operand panels); best of 3",
+                    "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                    "launch_us": 1e3 * best_c[0], "cells": best_c[2], "algorithmic_flops_per_launch": best_c[1],
+                    "traffic": traffic, "traffic_source": "profiles/r04_pmc_cell_kernel.json (rocprofv3 --pmc passes of tools/pmc_cell.sh), not measured in this run",
+                    "hbm_GBps_at_that_traffic": (traffic / (best_c[0] * 1e-3) / 1e9) if traffic else None}
+            check(lib.gprx_set_handle_tuning(h1, b"cell_kernel", -1), h1)
+            sizes["N1024_d8_roofline_launch_sequence"] = roofline_block(
                 h1, lambda: check(lib.gprx_factorize_batch(h1, c1, ptr(units1), ptr(thetas1), mask, ptr(losses1), ptr(status1)), h1),
-                "gemm_f64_kernel<0,1,64,64,0,0,1>: the K = 256 / 512 in-block updates of the LAUNCH SEQUENCE (the instrumented pass; the default at this size is the one-workgroup-per-cell kernel), 512 cells per launch (the whole matrix is one outer block)")
+                "gemm_f64_kernel<0,1,64,64,0,0,1>: the K = 256 / 512 in-block updates of the LAUNCH SEQUENCE (not the default at this size), 512 cells per launch (the whole matrix is one outer block)")
+            check(lib.gprx_set_handle_tuning(h1, b"cell_kernel", 0), h1)
             check(lib.gprx_factorize(h1, 0, ptr(theta), None, mask, C.byref(loss)), h1)
             t1 = time.perf_counter()
             for _ in range(10):

@@ -94,6 +94,9 @@ struct gprx_ctx {
   Buf apart;                                      // row-chunk partial sums of alpha_from_inverse
   hipEvent_t kev[2] = {nullptr, nullptr};         // profiling: events around the kernel-build launch
   double kmat_ms = 0.0, kmat_bytes = 0.0;
+  hipEvent_t cev[2] = {nullptr, nullptr};         // profiling: events around the one-workgroup-per-cell kernel's launch
+  bool cev_recorded = false;
+  double cell_ms = 0.0, cell_flops = 0.0, cell_cells = 0.0;
   Buf sarena;                                   // batched sparse models: one cell block per slot (sgpr_batch_layout)
   int sarena_slots = 0;
   double* spin = nullptr;  // pinned staging of the sparse batch: parameters up, reductions / gradients down
@@ -456,6 +459,12 @@ void summarize_profile(gprx_handle h) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->kev[0], h->kev[1]) == hipSuccess) h->kmat_ms = ms;
   }
+  h->cell_ms = 0.0;
+  if (h->cev_recorded) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->cev[0], h->cev[1]) == hipSuccess) h->cell_ms = ms;
+    h->cev_recorded = false;
+  }
   h->prof_out[5] = strip_ms;
   h->prof_out[6] = (double)h->prof.strip_marks.size();
   h->prof_out[7] = strip_flops;
@@ -607,7 +616,9 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     KmatArgs ka{h->X.p, h->X.p, nullptr, K0, ld, (int)h->n, (int)h->n, h->d, np, np, 0.0, 0.0, 1, 1.0, nullptr, 0};
     ka.cell_par = cpar;
     ka.out_stride = cs;
-    const bool cell_kernel = use_cell_kernel(h->tune, np, cnt) && !h->profiling;
+    // (under profiling the launch sequence is instrumented launch by launch; the cell kernel -- ONE launch -- is timed when the handle
+    // forces it, "cell_kernel" = 1: gprx_last_cell_kernel)
+    const bool cell_kernel = use_cell_kernel(h->tune, np, cnt) && (!h->profiling || h->tune.cell_kernel > 0);
     // (the column-pair cell kernel evaluates K where it consumes it: no build launch, nothing written but the right-hand-side rows)
     const bool cell_builds_k = cell_kernel && potrf_cells_builds_k(h->kid, h->dist_form, np, h->d);
     if (h->profiling) {
@@ -628,10 +639,23 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
     if (wait_evt) HIPCHK(h, hipStreamWaitEvent(gs, wait_evt, 0));
     if (cell_kernel) {
       // small matrices in many cells: one workgroup owns one cell from the first column to the last (potrf_cell.h)
+      if (h->profiling) {
+        if (!h->cev[0]) {
+          HIPCHK(h, hipEventCreate(&h->cev[0]));
+          HIPCHK(h, hipEventCreate(&h->cev[1]));
+        }
+        HIPCHK(h, hipEventRecord(h->cev[0], gs));
+      }
       if (cell_builds_k)
         HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES, 0, h->X.p, cpar, (int)h->n, h->d));
       else
         HIPCHK(h, potrf_cells(gs, K0, ld, np, NB, K0 + h->off_invd, info0, cnt, cs, 2 * CELL_RES));
+      if (h->profiling) {
+        HIPCHK(h, hipEventRecord(h->cev[1], gs));
+        h->cev_recorded = true;
+        h->cell_cells = cnt;
+        h->cell_flops = (double)np * np * np / 3.0 * cnt;  // algorithmic: N^3 / 3 per cell (the right-hand-side rows' N^2 not counted)
+      }
     } else {
       HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
                             2 * CELL_RES, &h->tune, 0, record_evt));
@@ -1511,6 +1535,8 @@ int gprx_destroy(gprx_handle h) {
   if (h->stagger_evt) hipEventDestroy(h->stagger_evt);
   for (auto& ev : h->kev)
     if (ev) hipEventDestroy(ev);
+  for (auto& ev : h->cev)
+    if (ev) hipEventDestroy(ev);
   if (h->info) hipFree(h->info);
   if (h->pin) hipHostFree(h->pin);
   if (h->gparams) hipFree(h->gparams);
@@ -1815,6 +1841,14 @@ int gprx_last_kernel_build(gprx_handle h, double* ms, double* bytes) {
   if (!h || !ms || !bytes) return fail(h, GPRX_EINVAL, "null argument");
   *ms = h->kmat_ms;
   *bytes = h->kmat_bytes;
+  return GPRX_OK;
+}
+
+int gprx_last_cell_kernel(gprx_handle h, double* ms, double* flops, double* cells) {
+  if (!h || !ms || !flops || !cells) return fail(h, GPRX_EINVAL, "null argument");
+  *ms = h->cell_ms;
+  *flops = h->cell_ms > 0.0 ? h->cell_flops : 0.0;
+  *cells = h->cell_ms > 0.0 ? h->cell_cells : 0.0;
   return GPRX_OK;
 }
 

@@ -15,7 +15,7 @@
 // potrf_lower to rounding (tested), not bit for bit.
 #pragma once
 #include "kmat.h"
-#include "potrf_dag.h"
+#include "tile_ops.h"
 
 namespace gprx {
 

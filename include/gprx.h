@@ -160,6 +160,11 @@ int gprx_last_profile(gprx_handle h, double* out8);
  * * cells) -- bench.py's kernel_build_hbm figure (north_star: "HBM GB/s on the kernel build"; reference: the K(X, X) inside
  * every training_loss, /root/reference/gpras/gpr.py:153-155). */
 int gprx_last_kernel_build(gprx_handle h, double* ms, double* bytes);
+/* The one-workgroup-per-cell Cholesky launch (potrf_cell.h: the default for many cells of N <= 1024) of the last PROFILED
+ * gprx_factorize_batch on a handle whose tuning forces it ("cell_kernel" = 1; without that a profiled batch runs the instrumented
+ * launch sequence): duration by HIP events around that ONE launch, its algorithmic flops (N^3 / 3 per cell) and the cell count;
+ * zeros when the last profiled call did not run it.  bench.py's other_sizes.N1024_d8_roofline. */
+int gprx_last_cell_kernel(gprx_handle h, double* ms, double* flops, double* cells);
 
 /* ---- batched small problems ------------------------------------------------------- */
 /* Evaluate loss (+ gradient) for `count` units in one call: units[i] with theta row i
