@@ -633,8 +633,10 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
       HIPCHK(h, hipEventRecord(h->kev[1], gs));
       h->kmat_bytes = 8.0 * KM_T * KM_T * (double)(np / KM_T) * (np / KM_T + 1) / 2 * cnt;
     }
-    hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
-                       (int)h->n, np, NB, cs);
+    // (the column-pair cell kernel carries the right-hand side as a vector: one row, of which it reads and writes the first np entries)
+    const bool beta_vector = cell_kernel && !cell_builds_k && potrf_cells_beta_vector(np, NB, false);
+    hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(beta_vector ? 4 : 64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
+                       (int)h->n, np, beta_vector ? 1 : NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
     if (wait_evt) HIPCHK(h, hipStreamWaitEvent(gs, wait_evt, 0));
     if (cell_kernel) {

@@ -59,6 +59,9 @@ struct CellArgs {
   const double* X = nullptr;
   const double* cell_par = nullptr;
   int n = 0, d = 0;
+  // column-pair kernel, R == T: beta = L^-1 y carried as a VECTOR (cell2_beta_*): cell 0's right-hand-side row (y on entry, beta on
+  // exit; cs apart), nullptr = the right-hand side rides as a 64-row tile below the matrix (R = T + 1)
+  double* beta = nullptr;
 };
 
 // the diagonal block (j, j): chain_step<0..7> on [64 diagonal rows | 64 identity rows] -> L(j,j) in place, L(j,j)^-1 to inv_diag
@@ -373,10 +376,18 @@ __device__ __forceinline__ void cell2_dma_block(const double* __restrict__ src, 
 // The streaming product of a pass: acc(t, c) += sum_{k < K} A(64 t + ., k) B(64 c + ., k)^T, A = NI row tiles at Arow, B = the two
 // tiles at Brow, both with leading dimension lda; SAME: A and B are the same panel (the pair's own rows: one image serves both, and
 // the tile above the diagonal, (t, c) = (0, 1), is left out).  16-deep stages, LDS-DMA, two buffers, one barrier per stage.
-template <int NI, bool SAME>
+// BETA (with SAME: the pair's own 128-row panel): the panel's product with the vector beta[0, K) rides along -- thread t owns row
+// t & 127 and the k half t >> 7 of every 16-deep stage image (8 fp64 FMAs per thread and stage beside 48 MFMAs per wave), its partial
+// sum comes back in `tsum`: what the forward substitution of the right-hand side needs from these rows, without a tile row of its own.
+template <int NI, bool SAME, bool BETA = false>
 __device__ __forceinline__ void cell2_stream(d4 (&acc)[NI][2][2][2], const double* __restrict__ Arow, const double* __restrict__ Brow, int64_t lda, int K,
-                                             double* __restrict__ smem, int lane, int wave_u, int wm, int wn, int g, int r) {
+                                             double* __restrict__ smem, int lane, int wave_u, int wm, int wn, int g, int r,
+                                             const double* __restrict__ sBeta = nullptr, double* tsum = nullptr) {
+  static_assert(!BETA || SAME, "the vector product is defined on the pair's own panel");
   const int swz = kc_swz(r);
+  const int brow = (wave_u & 1) * 64 + lane, bhalf = wave_u >> 1;  // (BETA) this thread's panel row and k half
+  const int bswz = kc_swz(brow);
+  double bsum = 0.0;
   auto dma_fill = [&](int k0, int buf) {
     double* sa = smem + buf * CELL2_STAGE;
     double* sb = sa + 2 * NB * GEMM_BK;
@@ -414,6 +425,15 @@ __device__ __forceinline__ void cell2_stream(d4 (&acc)[NI][2][2][2], const doubl
         const d2 hi = *reinterpret_cast<const d2*>(sb + col * GEMM_BK + 2 * ((2 * g + 1) ^ swz));
         fb[c][b][0] = lo.x; fb[c][b][1] = lo.y; fb[c][b][2] = hi.x; fb[c][b][3] = hi.y;
       }
+    if constexpr (BETA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const d2 pv = *reinterpret_cast<const d2*>(sb + brow * GEMM_BK + 2 * ((4 * bhalf + i) ^ bswz));
+        const d2 bv = *reinterpret_cast<const d2*>(sBeta + k0 + 8 * bhalf + 2 * i);
+        bsum = __builtin_fma(pv.x, bv.x, bsum);
+        bsum = __builtin_fma(pv.y, bv.y, bsum);
+      }
+    }
 #ifdef GPRX_CELL2_NOMMA
     acc[0][0][0][0][0] += fa[0][0][0] + fb[0][0][0] + fa[NI - 1][1][3] + fb[1][1][3];
 #else
@@ -443,6 +463,7 @@ __device__ __forceinline__ void cell2_stream(d4 (&acc)[NI][2][2][2], const doubl
       stage(k0 + GEMM_BK, 1);  // (K is a multiple of 64)
     }
   }
+  if constexpr (BETA) *tsum = bsum;
 }
 
 // what the solve steps share: accumulator layout <-> A stage images, the residual C - sum, tile stores
@@ -589,6 +610,82 @@ __device__ __forceinline__ void cell2_fetch(d4 (&v)[2][2], const TileCtx& p, int
     cell2_residual(v, p.A + (int64_t)ti * NB * p.lda + (int64_t)tj * NB, q);
 }
 
+// ---- beta = L^-1 y as a vector (round 4) ---------------------------------------------------------------------------------------------
+// The right-hand side used to ride as a 64-row tile below the matrix (one useful row of 64): Sum_j j = T^2 / 2 tile products plus a
+// 64 x 128 streaming pass per column pair -- at N = 1024 8 % of the launch, at N = 512 16 % (tools/batch_n1024.py with and without it:
+// 5.97 -> 5.52 ms, 1.56 -> 1.35 ms per 512 cells).  The forward substitution needs, per block column j, only
+//     beta_j = L(j,j)^-1 (y_j - Sum_{k < 64 j} L(j, k) beta_k),
+// and the panel L(j .. j+1, 0 .. 64 j) is exactly what cell2_diag_pair streams through LDS for the pair's own tiles: the panel-times-vector
+// product rides in that stream (cell2_stream<2, true, true>), then three 64 x 64 matrix-vector products per pair (two against the
+// inverses the chain leaves in memory, one against L(j+1, j)) finish the pair.  beta lives in LDS (at most 1024 entries: T <= 16) and
+// replaces y in the cell's right-hand-side row.  Sums of 64 j + 64 terms in fixed order: the loss agrees with the tile form to rounding.
+constexpr int CELL2_BETA_MAXT = 16;
+constexpr int CELL2_BETA_LDS = CELL2_BETA_MAXT * NB + 256 + 256 + NB;  // doubles: beta | the stream's partial sums | matrix-vector partials | a block's residual
+struct Cell2Beta {
+  double* y;      // global: this cell's right-hand-side row
+  double* sBeta;  // [CELL2_BETA_MAXT * NB]
+  double* sPart;  // [256]: row r of the pair, k half h at r + 128 h
+  double* sRed;   // [256]
+  double* sV;     // [NB]
+};
+// sRed[64 q + a] = Sum_{b in [16 q, 16 q + 16)} M[a][b] v[b]: M row-major in global memory (row stride ldm), v in LDS
+__device__ __forceinline__ void cell2_gemv64(const double* __restrict__ M, int64_t ldm, const double* __restrict__ v, double* __restrict__ sRed, int tid) {
+  const int a = tid & 63, q = tid >> 6;
+  const double* row = M + (int64_t)a * ldm + 16 * q;
+  d2 m[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = *reinterpret_cast<const d2*>(row + 2 * i);
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sum = __builtin_fma(m[i].x, v[16 * q + 2 * i], sum);
+    sum = __builtin_fma(m[i].y, v[16 * q + 2 * i + 1], sum);
+  }
+  sRed[tid] = sum;
+}
+__device__ __forceinline__ double cell2_red4(const double* __restrict__ sRed, int a) { return ((sRed[a] + sRed[64 + a]) + sRed[128 + a]) + sRed[192 + a]; }
+// block column jb: sV holds y_jb - (what the columns left of it contribute); beta_jb = L(jb,jb)^-1 sV -> sBeta and the cell's row
+__device__ __forceinline__ void cell2_beta_solve(const TileCtx& p, int jb, const Cell2Beta& bq, int tid) {
+  cell2_gemv64(p.inv_diag + (int64_t)jb * NB * NB, NB, bq.sV, bq.sRed, tid);
+  lds_barrier();
+  if (tid < NB) {
+    const double b = cell2_red4(bq.sRed, tid);
+    bq.sBeta[jb * NB + tid] = b;
+    bq.y[jb * NB + tid] = b;
+  }
+  lds_barrier();
+}
+// after the pair (j, j + 1) is factored (every store of the pair acknowledged: the caller's cell_sync); sPart = the stream's partial sums
+__device__ __forceinline__ void cell2_beta_pair(const TileCtx& p, int j, const Cell2Beta& bq, int tid) {
+  if (tid < NB) bq.sV[tid] = bq.y[j * NB + tid] - (bq.sPart[tid] + bq.sPart[128 + tid]);
+  lds_barrier();
+  cell2_beta_solve(p, j, bq, tid);
+  cell2_gemv64(p.A + (int64_t)(j + 1) * NB * p.lda + (int64_t)j * NB, p.lda, bq.sBeta + j * NB, bq.sRed, tid);
+  lds_barrier();
+  if (tid < NB) bq.sV[tid] = bq.y[(j + 1) * NB + tid] - ((bq.sPart[NB + tid] + bq.sPart[128 + NB + tid]) + cell2_red4(bq.sRed, tid));
+  lds_barrier();
+  cell2_beta_solve(p, j + 1, bq, tid);
+}
+// a single last block column j (T odd): its row panel L(j, 0 .. 64 j) times beta straight from memory
+__device__ __forceinline__ void cell2_beta_single(const TileCtx& p, int j, const Cell2Beta& bq, int tid) {
+  const int a = tid & 63, q = tid >> 6;
+  const double* row = p.A + ((int64_t)j * NB + a) * p.lda;
+  double sum = 0.0;
+  for (int k = 16 * q; k < j * NB; k += 64) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const d2 m = *reinterpret_cast<const d2*>(row + k + 2 * i);
+      sum = __builtin_fma(m.x, bq.sBeta[k + 2 * i], sum);
+      sum = __builtin_fma(m.y, bq.sBeta[k + 2 * i + 1], sum);
+    }
+  }
+  bq.sRed[tid] = sum;
+  lds_barrier();
+  if (tid < NB) bq.sV[tid] = bq.y[j * NB + tid] - cell2_red4(bq.sRed, tid);
+  lds_barrier();
+  cell2_beta_solve(p, j, bq, tid);
+}
+
 // row tiles i0 .. i0 + NI - 1 (all below tile row j + 1) of the block columns j and j + 1
 template <int NI, bool KB>
 __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, const Cell2K& kq, double* __restrict__ smem) {
@@ -651,8 +748,8 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, cons
 // single-column kernel does as three latency-bound passes of one tile product per step: the diagonal update of j, update + solve of
 // (j + 1, j), the diagonal update of j + 1), then the two chains and the solve between them.  Returns the failing pivot (1-based,
 // within the pair's 128 columns) or 0.
-template <bool KB>
-__device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, const Cell2K& kq, double* __restrict__ smem) {
+template <bool KB, bool BETA = false>
+__device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, const Cell2K& kq, double* __restrict__ smem, const Cell2Beta* bq = nullptr) {
   const int tid = cell_tid(), lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   Cell2Lane q;
@@ -666,7 +763,13 @@ __device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, const Ce
 #pragma unroll
     for (int c = 0; c < 2; ++c) cell2_zero(acc[t][c]);
   const double* Prow = p.A + (int64_t)j * NB * p.lda;
-  cell2_stream<2, true>(acc, Prow, Prow, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r);
+  if constexpr (BETA) {
+    double tsum = 0.0;
+    cell2_stream<2, true, true>(acc, Prow, Prow, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r, bq->sBeta, &tsum);
+    bq->sPart[tid] = tsum;  // (read by cell2_beta_pair, several barriers from here)
+  } else {
+    cell2_stream<2, true>(acc, Prow, Prow, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r);
+  }
   auto tile = [&](int i, int jc) { return p.A + (int64_t)i * NB * p.lda + (int64_t)jc * NB; };
   double* inv = const_cast<double*>(p.inv_diag);
   double* sA = smem;
@@ -700,12 +803,15 @@ __device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, const Ce
 #ifndef GPRX_CELL2_OCC
 #define GPRX_CELL2_OCC 2
 #endif
-template <bool KB>
+template <bool KB, bool BETA = false>
 __global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellArgs p) {
+  static_assert(!(KB && BETA), "two workgroups per CU: the LDS holds either the kernel-build staging or the beta vector");
   __shared__ __attribute__((aligned(16))) double smem[KB ? CELL2_SMEM_K : DAG_SMEM];
+  __shared__ __attribute__((aligned(16))) double sbeta[BETA ? CELL2_BETA_LDS : 2];
   const int64_t off = (int64_t)blockIdx.x * p.cs;
   const TileCtx tc{p.A + off, p.lda, p.inv_diag + off};
   const Cell2K kq{p.X, p.cell_par + (int64_t)blockIdx.x * CELL_PAR, p.n, p.d, p.T};
+  const Cell2Beta bq{BETA ? p.beta + off : nullptr, sbeta, sbeta + CELL2_BETA_MAXT * NB, sbeta + CELL2_BETA_MAXT * NB + 256, sbeta + CELL2_BETA_MAXT * NB + 512};
   if (KB) exp_tab_fill(smem + CELL2_KX + 64 * KM_DC + KM_DC * KM_BT_LD);  // (visible after the first barrier of the first tile's staging)
   int first_bad = 0;
   for (int j = 0; j < p.T; j += 2) {
@@ -717,15 +823,17 @@ __global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellAr
       const int bad = cell_diag(tc.A + (int64_t)j * NB * p.lda + (int64_t)j * NB, p.lda, const_cast<double*>(tc.inv_diag) + (int64_t)j * NB * NB, smem);
       if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
       cell_sync();
+      if constexpr (BETA) cell2_beta_single(tc, j, bq, cell_tid());
       for (int i0 = j + 1; i0 < p.R; i0 += CELL_NI) {
         cell_panel_fused(tc, i0, p.R - i0 < CELL_NI ? p.R - i0 : CELL_NI, j, smem);
         cell_sync();
       }
       break;
     }
-    const int bad = cell2_diag_pair<KB>(tc, j, kq, smem);
+    const int bad = cell2_diag_pair<KB, BETA>(tc, j, kq, smem, &bq);
     if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
     cell_sync();
+    if constexpr (BETA) cell2_beta_pair(tc, j, bq, cell_tid());
 #ifndef GPRX_CELL2_NOROWS
     int i0 = j + 2;
     for (; i0 + 1 < p.R; i0 += 2) {
@@ -756,6 +864,16 @@ inline bool potrf_cells_builds_k(int kid, int form, int np, int d) {
 
 // build_k: X / cell_par / n / d given and potrf_cells_builds_k() holds -- the matrices need not have been written (only their
 // right-hand-side rows)
+// Does potrf_cells carry the right-hand side as a VECTOR (cell2_beta_*: the default form, one right-hand-side row of which only the first
+// np entries are read and written) instead of 64 tile rows?  GPRX_CELL_BETA_ROWS=1 restores the tile form (A/B, bit-for-bit tests
+// against the other kernel forms, which only know the tile form).
+inline bool potrf_cells_beta_vector(int np, int extra, bool builds_k) {
+  static const bool off = (getenv("GPRX_CELL_BETA_ROWS") && atoi(getenv("GPRX_CELL_BETA_ROWS")) != 0) ||
+                          (getenv("GPRX_CELL_TWO_PASS") && atoi(getenv("GPRX_CELL_TWO_PASS")) != 0) ||
+                          (getenv("GPRX_CELL_SINGLE_COLUMN") && atoi(getenv("GPRX_CELL_SINGLE_COLUMN")) != 0);
+  return !off && !builds_k && extra == NB && np / NB <= CELL2_BETA_MAXT;
+}
+
 inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info, int batch, int64_t cs,
                               int info_stride, int col_base = 0, const double* X = nullptr, const double* cell_par = nullptr, int n = 0, int d = 0) {
   CellArgs a;
@@ -780,6 +898,10 @@ inline hipError_t potrf_cells(hipStream_t st, double* A, int64_t lda, int np, in
     a.n = n;
     a.d = d;
     hipLaunchKernelGGL(potrf_cell2_kernel<true>, dim3(batch), dim3(256), 0, st, a);
+  } else if (potrf_cells_beta_vector(np, extra, false)) {
+    a.R = a.T;
+    a.beta = A + (int64_t)np * lda;
+    hipLaunchKernelGGL((potrf_cell2_kernel<false, true>), dim3(batch), dim3(256), 0, st, a);
   } else
     hipLaunchKernelGGL(potrf_cell2_kernel<false>, dim3(batch), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -143,13 +143,21 @@ def test_cell_kernel_forms_agree_bit_for_bit():
     column-pair kernel (round 4: two block columns per pass on LDS-DMA operand panels, potrf_cell.h cell2_rows; also with the kernel matrix
     evaluated inside the kernel, GPRX_CELL_BUILD_K=1) -- perform the same tile products on the same operands in the same accumulation
     order: the losses are equal to the last bit."""
+    import json
+
     outs = []
-    for env in ({"GPRX_CELL_TWO_PASS": "1"}, {"GPRX_CELL_SINGLE_COLUMN": "1"}, {}, {"GPRX_CELL_BUILD_K": "1"}):
-        base = {k: v for k, v in os.environ.items() if k not in ("GPRX_CELL_TWO_PASS", "GPRX_CELL_SINGLE_COLUMN")}
+    # (GPRX_CELL_BUILD_K applies to even block-column counts only; the odd cases of that run take the plain kernel, pinned to the tile form too)
+    for env in ({"GPRX_CELL_TWO_PASS": "1"}, {"GPRX_CELL_SINGLE_COLUMN": "1"}, {"GPRX_CELL_BETA_ROWS": "1"}, {"GPRX_CELL_BUILD_K": "1", "GPRX_CELL_BETA_ROWS": "1"}, {}):
+        base = {k: v for k, v in os.environ.items() if not k.startswith("GPRX_CELL")}
         res = subprocess.run([sys.executable, "-c", TWO_PASS.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=dict(base, **env))
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] == outs[2] == outs[3]
+    # the default form carries the right-hand side as a VECTOR (cell2_beta_*: beta = L^-1 y by matrix-vector products on the same factor,
+    # no tile row): the factor and log det are those bits, y^T K^-1 y = |beta|^2 is summed in another order -- equal to rounding
+    tiles = np.array([float.fromhex(v) for v in json.loads(outs[2])])
+    vector = np.array([float.fromhex(v) for v in json.loads(outs[4])])
+    assert np.max(np.abs(vector - tiles) / np.abs(tiles)) <= 1e-14
 
 
 FULL_LOAD = r"""
@@ -197,10 +205,11 @@ def test_cell_kernels_at_full_load_two_workgroups_per_cu():
     assert seq[0] == seq[1] == seq[2]
     ref = np.array([float.fromhex(v) for v in seq[0]])
     first = None
-    for env in ({}, {"GPRX_CELL_SINGLE_COLUMN": "1"}, {"GPRX_CELL_TWO_PASS": "1"}, {"GPRX_CELL_BUILD_K": "1"}):
+    for env in ({"GPRX_CELL_BETA_ROWS": "1"}, {"GPRX_CELL_SINGLE_COLUMN": "1"}, {"GPRX_CELL_TWO_PASS": "1"}, {"GPRX_CELL_BUILD_K": "1", "GPRX_CELL_BETA_ROWS": "1"}, {}):
         got = run(1, env)
         assert got[0] == got[1] == got[2], env
         first = first or got[0]
-        assert got[0] == first, env
+        if env:  # (the default form's right-hand side is a vector: same factor, another summation order -- equal to rounding, checked below)
+            assert got[0] == first, env
         vals = np.array([float.fromhex(v) for v in got[0]])
         assert np.max(np.abs(vals - ref) / np.abs(ref)) <= 1e-13, env
