@@ -663,11 +663,11 @@ def main():
                 traffic = None
                 try:
                     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_cell_kernel.json")) as f:
-                        traffic = float(json.load(f)["kernels"]["potrf_cell2_kernel<false>"]["hbm_bytes_per_launch_corrected"])
+                        traffic = float(next(v for k, v in json.load(f)["kernels"].items() if k.startswith("potrf_cell2_kernel"))["hbm_bytes_per_launch_corrected"])
                 except Exception:  # noqa: BLE001
                     pass
                 sizes["N1024_d8_roofline"] = {
-                    "kernel": "gprx::potrf_cell2_kernel<false>: the whole Cholesky of 512 cells of N = 1024 (+ 64 right-hand-side rows) in ONE launch, one workgroup per cell (column pairs, LDS-DMA operand panels); best of 3",
+                    "kernel": "gprx::potrf_cell2_kernel<false,true>: the whole Cholesky of 512 cells of N = 1024 and the forward substitution of their right-hand sides in ONE launch, one workgroup per cell (column pairs, LDS-DMA operand panels); best of 3",
                     "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                     "launch_us": 1e3 * best_c[0], "cells": best_c[2], "algorithmic_flops_per_launch": best_c[1],
                     "traffic": traffic, "traffic_source": "profiles/r04_pmc_cell_kernel.json (rocprofv3 --pmc passes of tools/pmc_cell.sh), not measured in this run",
