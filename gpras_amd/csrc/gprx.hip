@@ -634,7 +634,9 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
       h->kmat_bytes = 8.0 * KM_T * KM_T * (double)(np / KM_T) * (np / KM_T + 1) / 2 * cnt;
     }
     // (the column-pair cell kernel carries the right-hand side as a vector: one row, of which it reads and writes the first np entries)
-    const bool beta_vector = cell_kernel && !cell_builds_k && potrf_cells_beta_vector(np, NB, false);
+    // (so does the launch sequence's split panel: potrf_rows_kernel<..., YVEC>)
+    const bool rhs_vector = !cell_kernel && potrf_rhs_vector_ok(h->tune, cnt);
+    const bool beta_vector = rhs_vector || (cell_kernel && !cell_builds_k && potrf_cells_beta_vector(np, NB, false));
     hipLaunchKernelGGL(set_rhs_rows_batch_kernel, dim3(beta_vector ? 4 : 64, cnt), dim3(256), 0, gs, K0 + (int64_t)np * ld, ld, (const double*)h->Y.p, cpar,
                        (int)h->n, np, beta_vector ? 1 : NB, cs);
     int* info0 = reinterpret_cast<int*>(cres + 2);
@@ -659,8 +661,8 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
         h->cell_flops = (double)np * np * np / 3.0 * cnt;  // algorithmic: N^3 / 3 per cell (the right-hand-side rows' N^2 not counted)
       }
     } else {
-      HIPCHK(h, potrf_lower(gs, K0, ld, np, NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
-                            2 * CELL_RES, &h->tune, 0, record_evt));
+      HIPCHK(h, potrf_lower(gs, K0, ld, np, rhs_vector ? 0 : NB, K0 + h->off_invd, info0, K0 + h->off_stage, h->profiling ? &h->prof : nullptr, nullptr, cnt, cs,
+                            2 * CELL_RES, &h->tune, 0, record_evt, rhs_vector ? K0 + (int64_t)np * ld : nullptr));
     }
     const double* beta = K0 + (int64_t)np * ld;
     if (with_alpha) hipLaunchKernelGGL(copy_row_batch_kernel, dim3((np + 255) / 256, cnt), dim3(256), 0, gs, beta, K0 + h->off_alpha, np, cs);
@@ -3005,6 +3007,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "inblock" && (value == 0 || value == 1)) t.inblock = value;
   else if (k == "split_panel" && value >= -1 && value <= 1) t.split_panel = value;
   else if (k == "dag" && value >= -1 && value <= 1) t.dag = value;
+  else if (k == "rhs_vector" && value >= -1 && value <= 1) t.rhs_vector = value;
   else if (k == "rows_inv" && value >= -1 && value <= 1) t.rows_inv = value;
   else if (k == "rows_inv_rt" && value >= 0 && value <= 2) t.rows_inv_rt = value;
   else if (k == "rows_inv_lone" && value >= 0 && value <= 1) t.rows_inv_lone = value;

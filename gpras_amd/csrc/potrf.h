@@ -220,7 +220,8 @@ template <int RT, int OCC, bool FUSE_K64 = false>
 __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restrict__ A, int64_t lda, int rows_below, int nchunks,
                                                           double* __restrict__ inv_diag, int* __restrict__ info, int col0,
                                                           double* __restrict__ stage_out, const double* __restrict__ prev_stage,
-                                                          double* __restrict__ prev_dst, int prev_pw, int64_t cs, int info_stride) {
+                                                          double* __restrict__ prev_dst, int prev_pw, int64_t cs, int info_stride,
+                                                          double* __restrict__ yv = nullptr) {
   constexpr int PWG_ROWS = PanelGeom<RT>::kWgRows;
   constexpr int PANEL_ROWS = PanelGeom<RT>::kOwnRows;
   constexpr int WROWS = 16 * RT;
@@ -398,6 +399,27 @@ __global__ __launch_bounds__(256, OCC) void potrf_panel_kernel(double* __restric
       }
   }
   if (last && c.tid == 0 && c.bad != 0) atomicCAS(info, 0, col0 + c.bad);
+  if (yv != nullptr && last) {
+    // Right-hand side as a vector (potrf_rows_kernel<..., YVEC>): beta_j = L11^-1 y_j by the diagonal workgroup itself, from the inverse
+    // its identity rows have just stored (every wave's stores acknowledged, then the barrier; nobody read those lines before).  Row a of
+    // the inverse times y_j: four partial sums of 16 terms, added in a fixed order.
+    yv += (int64_t)blockIdx.y * cs;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double* sv = sIn;         // (the sub-panel buffers are free now)
+    double* sred = sIn + NB;
+    static_assert(PWG_ROWS * PSUB >= NB + 256, "the sub-panel buffer holds y_j and the partial sums");
+    if (c.tid < NB) sv[c.tid] = yv[c.tid];
+    __syncthreads();
+    const int a = c.tid & 63, qq = c.tid >> 6;
+    const double* row = inv_diag + a * NB + 16 * qq;
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum = __builtin_fma(row[i], sv[16 * qq + i], sum);
+    sred[c.tid] = sum;
+    __syncthreads();
+    if (c.tid < NB) yv[c.tid] = ((sred[c.tid] + sred[64 + c.tid]) + sred[128 + c.tid]) + sred[192 + c.tid];
+  }
   PSTAMP(5)
   PACC(5)
 }
@@ -492,9 +514,14 @@ __device__ __forceinline__ void rows_step(d4 (&acc)[RT][4], double* __restrict__
 // launch that update is HBM-bound (16 bytes of C traffic per 128 flops), and this kernel reads and writes the very same columns
 // anyway.  Operation for operation the general NT kernel's arithmetic (accumulators from zero, stages of 16 along k, instruction j
 // takes k = k0 + 4 g + j, C + (-1) * sum with one rounding): bit-identical to the separate launch.
-template <int RT, int OCC, bool SCALAR_L = false, bool NO_LDS_L = false, bool WAVE_LOCAL = false, bool FUSE_K64 = false>
+// YVEC (round 4): the right-hand side of the cell travels as a VECTOR instead of a 64-row tile below the matrix (one useful row of 64:
+// T^2 / 2 tile products of a factorisation with T block columns, 4.5 % of the flops at N = 4096).  yv points at this panel's 64 entries
+// of it -- beta_j = L11^-1 y_j, written by potrf_beta_block_kernel between the diagonal workgroup and this launch -- followed by the
+// entries of the rows below, which this kernel updates: y_i -= sum_c L(i, c) beta_j[c], the 64 products of a row summed over the tile
+// columns in a lane (k t ascending) and then over the 16 lanes that hold the row (xor 1, 2, 4, 8): a fixed order.
+template <int RT, int OCC, bool SCALAR_L = false, bool NO_LDS_L = false, bool WAVE_LOCAL = false, bool FUSE_K64 = false, bool YVEC = false>
 __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict__ A21, int64_t lda, int rows_below,
-                                                              const double* __restrict__ stage, int64_t cs) {
+                                                              const double* __restrict__ stage, int64_t cs, double* __restrict__ yv = nullptr) {
   constexpr int WG_ROWS = 64 * RT, WROWS = 16 * RT;
   __shared__ __attribute__((aligned(16))) double sIn[WG_ROWS * PSUB];
   __shared__ __attribute__((aligned(16))) double sX[WG_ROWS * PSUB];
@@ -594,6 +621,21 @@ __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict
   rows_step<3, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
   rows_step<4, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
   rows_step<5, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
+  // (YVEC: beta_j and this lane group's entries of y are requested before the last two sub-panel steps -- their latency hides behind
+  // those -- and only stored at the end; not earlier, the registers are needed)
+  double ybj[YVEC ? 4 : 1], yold[YVEC ? RT : 1][4];
+  if constexpr (YVEC) {
+    yv += (int64_t)blockIdx.y * cs;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) ybj[kt] = yv[16 * kt + r];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = row0 + WROWS * wave + 16 * rt + g + 4 * q;
+        yold[rt][q] = yv[NB + (idx < rows_below ? idx : 0)];
+      }
+  }
   rows_step<6, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
   rows_step<7, RT, SCALAR_L, WAVE_LOCAL>(acc, sIn, sX, sL, sRinv, tid, wave, g, r, stage);
 #pragma unroll
@@ -607,6 +649,39 @@ __global__ __launch_bounds__(256, OCC) void potrf_rows_kernel(double* __restrict
         for (int kt = 0; kt < 4; ++kt) dst[kt * 16] = acc[rt][kt][q];
       }
     }
+  if constexpr (YVEC) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double sum = acc[rt][0][q] * ybj[0];
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt) sum = __builtin_fma(acc[rt][kt][q], ybj[kt], sum);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m, 64);
+        const int idx = row0 + WROWS * wave + 16 * rt + g + 4 * q;
+        if (r == 0 && idx < rows_below) yv[NB + idx] = yold[rt][q] - sum;
+      }
+  }
+}
+
+// beta_j = L11^-1 y_j for the panel at hand (YVEC above): one workgroup per cell, between the diagonal workgroup (which leaves L11^-1 in
+// inv_diag) and the rows kernel.  Row a of the inverse times y_j, four partial sums of 16 terms added in a fixed order.
+__global__ __launch_bounds__(256) void potrf_beta_block_kernel(const double* __restrict__ inv, double* __restrict__ yv, int64_t cs) {
+  __shared__ double sv[NB];
+  __shared__ double sred[256];
+  inv += (int64_t)blockIdx.y * cs;
+  yv += (int64_t)blockIdx.y * cs;
+  const int tid = threadIdx.x, a = tid & 63, q = tid >> 6;
+  if (tid < NB) sv[tid] = yv[tid];
+  __syncthreads();
+  const double* row = inv + a * NB + 16 * q;
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum = __builtin_fma(row[i], sv[16 * q + i], sum);
+  sred[tid] = sum;
+  __syncthreads();
+  if (tid < NB) yv[tid] = ((sred[tid] + sred[64 + tid]) + sred[128 + tid]) + sred[192 + tid];
 }
 
 // ---- split panel, rows by ONE tile product against the diagonal block's inverse (round 4) ----------------------------------
@@ -1170,6 +1245,7 @@ struct PotrfTuning {
   int split_updates = 0; // lone matrix: 1 = look-ahead split of the K >= 256 updates over a side stream (see potrf_lower; measured
                          // slower: 2.17 -> 2.66 ms at N = 4096), 0 = every update whole on the main stream (default)
   int cell_kernel = 0;   // batched cells: 1 = always one workgroup per cell (potrf_cell.h), -1 never, 0 = for np <= 1024 and >= 256 cells
+  int rhs_vector = 0;    // batched cells, split panel: -1 = the right-hand side always rides as a 64-row tile; 0 / 1 = as a vector where the schedule knows it
   int rows_inv = 0;      // split panel: 1 = rows below the diagonal block by one MFMA tile product against L11^-1 (potrf_rows_inv_kernel), 0 / -1 = substitution
   int rows_inv_rt = 0;   // 16-row tiles per wave of that kernel: 1 (default) or 2
   int rows_inv_lone = 0; // 1 = a lone matrix takes the split panel + rows_inv too (experiments at N >= 8192)
@@ -1186,6 +1262,7 @@ inline PotrfTuning& potrf_tuning() {
     if (const char* e = getenv("GPRX_INBLOCK")) v.inblock = atoi(e);
     if (const char* e = getenv("GPRX_SPLIT_PANEL")) v.split_panel = atoi(e);
     if (const char* e = getenv("GPRX_DAG")) v.dag = atoi(e);
+    if (const char* e = getenv("GPRX_RHS_VECTOR")) v.rhs_vector = atoi(e);
     if (const char* e = getenv("GPRX_ROWS_INV")) v.rows_inv = atoi(e);
     if (const char* e = getenv("GPRX_ROWS_INV_RT")) v.rows_inv_rt = atoi(e);
     if (const char* e = getenv("GPRX_ROWS_INV_LONE")) v.rows_inv_lone = atoi(e);
@@ -1231,6 +1308,17 @@ struct PotrfStreams {
   }
 };
 
+// Can potrf_lower carry ONE right-hand side as a vector (yvec; then extra = 0) under this tuning and batch size?  Only the default split
+// panel of batched cells knows the form (the diagonal workgroup + potrf_beta_block_kernel + potrf_rows_kernel<..., YVEC>); a lone or
+// small-batch factorisation (fused panel) keeps the 64-row tile, whose arithmetic is the one single calls are bit-identical in.
+// "rhs_vector": 1 / 0 = where possible (default), -1 = never.
+inline bool potrf_rhs_vector_ok(const PotrfTuning& tune, int batch) {
+  static const bool rows_lds = getenv("GPRX_ROWS_LDS") != nullptr;
+  const bool split_panel = tune.split_panel ? tune.split_panel > 0 : batch >= 24;
+  return tune.rhs_vector >= 0 && split_panel && batch > 1 && !rows_lds && tune.rows_inv <= 0 && tune.panel_width != PW && tune.panel_rows != 256 &&
+         tune.panel_occ != 3 && tune.inblock != 1;
+}
+
 // Factor the (np x np) matrix in place; `extra` rows below it are carried as right-hand sides.
 // inv_diag: np/64 blocks of 64 x 64.  info (device int) must be zeroed by the caller.
 //
@@ -1253,7 +1341,8 @@ struct PotrfStreams {
 // info words info_stride ints apart; every launch carries the cell index in blockIdx.y.
 inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, int extra, double* inv_diag, int* info,
                               double* diag_stage, PotrfProfile* prof = nullptr, PotrfStreams* ps = nullptr, int batch = 1, int64_t cs = 0,
-                              int info_stride = 0, const PotrfTuning* tune_in = nullptr, int col_base = 0, hipEvent_t first_block_evt = nullptr) {
+                              int info_stride = 0, const PotrfTuning* tune_in = nullptr, int col_base = 0, hipEvent_t first_block_evt = nullptr,
+                              double* yvec = nullptr) {
   const double* prev_stage = nullptr;
   double* prev_dst = nullptr;
   int prev_pw = 0;
@@ -1357,12 +1446,19 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
                          stage_out, prev_stage, prev_dst, prev_pw, cs, info_stride);
     } else if (split_panel) {
       // diagonal block: one workgroup per cell (the `last` role of the panel kernel: L11 staged, L11^-1, pivots) ...
+      // (right-hand side as a vector: beta_j = L11^-1 y_j at the end of the diagonal workgroup -- or, GPRX_BETA_BLOCK_KERNEL=1, by a launch
+      // of its own: same sums --, then the rows kernel takes L21 beta_j off the entries below)
+      static const bool beta_launch = getenv("GPRX_BETA_BLOCK_KERNEL") && atoi(getenv("GPRX_BETA_BLOCK_KERNEL")) != 0;
+      const bool yv_on = yvec != nullptr;
+      double* yv = yv_on ? yvec + c : nullptr;
+      double* yv_diag = (yv_on && !beta_launch) ? yv : nullptr;
       if (fuse)
         hipLaunchKernelGGL((potrf_panel_kernel<2, 2, true>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out,
-                           prev_stage, prev_dst, prev_pw, cs, info_stride);
+                           prev_stage, prev_dst, prev_pw, cs, info_stride, yv_diag);
       else
         hipLaunchKernelGGL((potrf_panel_kernel<2, 2>), dim3(1, batch), dim3(256), 0, st, Acc, lda, 0, 0, invd, info, col_base + c, stage_out, prev_stage,
-                           prev_dst, prev_pw, cs, info_stride);
+                           prev_dst, prev_pw, cs, info_stride, yv_diag);
+      if (yv_on && beta_launch) hipLaunchKernelGGL(potrf_beta_block_kernel, dim3(1, batch), dim3(256), 0, st, (const double*)invd, yv, cs);
       // ... then the rows below it, 128 per workgroup
       if (rows_below > 0) {
         // default: no L11 image in LDS (the 8 x 8 diagonal sub-blocks and pivots through scalar loads, the MFMA operands straight
@@ -1382,6 +1478,12 @@ inline hipError_t potrf_lower(hipStream_t st, double* A, int64_t lda, int np, in
           hipLaunchKernelGGL((potrf_rows_inv_kernel<2, 2, true>), grid_inv, dim3(256), 0, st, Acc + (int64_t)NB * lda, lda, rows_below, (const double*)invd, cs);
         else if (rows_inv)
           hipLaunchKernelGGL((potrf_rows_inv_kernel<2, 2>), grid_inv, dim3(256), 0, st, Acc + (int64_t)NB * lda, lda, rows_below, (const double*)invd, cs);
+        else if (fuse && yv_on)
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 2, true, true, true, true, true>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
+                             Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs, yv);
+        else if (yv_on)
+          hipLaunchKernelGGL((potrf_rows_kernel<2, 4, true, true, true, false, true>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
+                             Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs, yv);
         else if (fuse)
           hipLaunchKernelGGL((potrf_rows_kernel<2, 2, true, true, true, true>), dim3((rows_below + ROWS_WG - 1) / ROWS_WG, batch), dim3(256), 0, st,
                              Acc + (int64_t)NB * lda, lda, rows_below, (const double*)stage_out, cs);

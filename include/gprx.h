@@ -128,7 +128,11 @@ int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const
  * Results are bit-identical to gprx_factorize on each cell -- except where many SMALL matrices take the one-workgroup-per-cell
  * factorisation (default: N <= 256 from 32 cells, N <= 512 from 160, N <= 1024 from 256; tuning key "cell_kernel" = -1 forbids it,
  * 1 forces it): the same tile products with a tile's whole update formed as one sum, equal to the launch sequence to rounding
- * (1e-13 relative on the loss, tests/test_gpu_cells.py).  The factorisations stay resident in slots 0..count-1
+ * (1e-13 relative on the loss, tests/test_gpu_cells.py); and from 24 cells per launch on (the split panel) the right-hand side y of a
+ * cell travels as a VECTOR through the launch sequence instead of a 64-row tile below the matrix (4.5 % fewer flops at N = 4096): the
+ * factor and log det are gprx_factorize's bits, beta = L^-1 y and with it y^T K^-1 y are summed in another fixed order (1e-14 relative
+ * on the loss, 1e-12 on gradients; tuning key "rhs_vector" = -1 keeps the tile and with it the single call's bits).
+ * The factorisations stay resident in slots 0..count-1
  * until the next batch; gprx_select_slot makes one of them current for gprx_predict / gprx_predict_dev. */
 int gprx_factorize_batch(gprx_handle h, int count, const int* units, const double* thetas, int mask, double* losses, int* status);
 int gprx_select_slot(gprx_handle h, int slot);
@@ -358,6 +362,11 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * (1: always one diagonal workgroup + a rows-only kernel per panel, -1: never; default: from 24 cells per launch on).
  * "cell_kernel" (1: batched cells always take the one-workgroup-per-cell factorisation, -1: never; default by size, see
  * gprx_factorize_batch).
+ * "rhs_vector" (-1: batched cells always carry their right-hand side as a 64-row tile below the matrix, as single calls do; default 0:
+ * as a vector wherever the split panel runs -- potrf_rows_kernel<..., YVEC>; see gprx_factorize_batch).
+ * "rows_inv" (1: the split panel solves the rows below a diagonal block by ONE MFMA tile product against the block's explicit inverse
+ * (potrf_rows_inv_kernel) instead of the eight-step substitution: equal to rounding, not bit for bit; "rows_inv_rt" = 1 | 2 sixteen-row
+ * tiles per wave, "rows_inv_lone" = 1: a lone matrix takes the split panel too.  Opt-in: measured no faster).
  * "split_updates" (1: ONE matrix's in-block and HEAD updates with K >= 256 are split by columns -- the 64 columns the next panel
  * needs on the main stream, the rest in dyadic pieces on a side stream behind events; bit-identical factor, measured slower).
  * "dag" (1: ONE matrix is factored by the tile-DAG kernel -- a single persistent launch, the dependent chain of diagonal

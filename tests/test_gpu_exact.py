@@ -192,7 +192,9 @@ def test_factorize_batch_bit_identical_and_selectable(lib, kernel, n, d, ard, ce
             for c in range(count):
                 single = C.c_double()
                 check(lib.gprx_factorize(h, int(units[c]), ptr(np.ascontiguousarray(thetas[c])), None, ALL, C.byref(single)), h)
-                assert single.value == losses[c]
+                # (from 24 cells per launch on -- the split panel -- the right-hand side travels as a vector, round 4: the factor and log det
+                # are the single call's bits, y^T K^-1 y is summed in another order)
+                assert single.value == losses[c] or (count >= 24 and abs(single.value - losses[c]) <= 1e-14 * abs(single.value))
         assert lib.gprx_select_slot(h, 99) == _lib.GPRX_EINVAL
     finally:
         lib.gprx_destroy(h)

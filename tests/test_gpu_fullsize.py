@@ -40,11 +40,22 @@ def test_c2_n4096_32_cell_batch_loss_gradient_predict(lib):
         units = np.arange(cells, dtype=np.int32)
         losses, grads = np.zeros(cells), np.zeros((cells, 3))
         check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, 7, ptr(losses), ptr(grads)), h)
-        # every cell of the batch equals the single call bit for bit (same kernels, cell index in the grid)
+        # every cell of the batch equals the single call: the factor bit for bit (same kernels, cell index in the grid), the right-hand
+        # side to rounding -- at 32 cells per launch it travels as a vector (round 4: no 64-row tile below the matrix), a single call
+        # keeps the tile -- so the loss agrees to 1e-14 and the gradient, which contains alpha alpha^T, to 1e-12; with "rhs_vector" = -1
+        # (the tile form everywhere) both are the single call's bits
         for c in (0, 7, 19, 31):
             one, g1 = C.c_double(), np.zeros(3)
             check(lib.gprx_objective(h, c, ptr(thetas[c]), None, 7, C.byref(one), ptr(g1)), h)
-            assert one.value == losses[c] and np.array_equal(g1, grads[c]), c
+            assert abs(one.value - losses[c]) <= 1e-14 * abs(one.value) and np.max(np.abs(g1 - grads[c])) <= 1e-12 * np.max(np.abs(g1)), c
+        check(lib.gprx_set_handle_tuning(h, b"rhs_vector", -1), h)
+        tl, tg = np.zeros(cells), np.zeros((cells, 3))
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), None, 7, ptr(tl), ptr(tg)), h)
+        for c in (0, 7, 19, 31):
+            one, g1 = C.c_double(), np.zeros(3)
+            check(lib.gprx_objective(h, c, ptr(thetas[c]), None, 7, C.byref(one), ptr(g1)), h)
+            assert one.value == tl[c] and np.array_equal(g1, tg[c]), c
+        check(lib.gprx_set_handle_tuning(h, b"rhs_vector", 0), h)
         # sampled cells against the oracle: loss 1e-9, gradient 1e-7, predictions 1e-8
         flosses, status = np.zeros(cells), np.zeros(cells, dtype=np.int32)
         check(lib.gprx_factorize_batch(h, cells, ptr(units), ptr(thetas), 7, ptr(flosses), ptr(status)), h)
