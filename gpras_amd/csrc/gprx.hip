@@ -1948,6 +1948,10 @@ int gprx_objective_batch(gprx_handle h, int count, const int* units, const doubl
 }
 
 static constexpr int PRED_TILE = 8192;
+// test points per pass of ONE exact model's predict: the N x tile blocks Ks and V = L^-1 Ks stay at the 268 MB each they have at N = 4096,
+// so a small model takes more points per pass (N = 1024: 13 passes of 7 692 points with four launches each spent 21 % of the predict outside
+// the product; per-point results do not depend on the pass they fall into)
+static inline int pred_tile_for(int64_t np) { return np <= 1024 ? 4 * PRED_TILE : (np <= 2048 ? 2 * PRED_TILE : PRED_TILE); }
 
 // what one exact factorisation contributes to a prediction through the explicit inverse: alpha, L^-1, the kernel's
 // hyperparameters (a device lengthscale vector, or a row of the cell-parameter table) and the variance offset
@@ -2032,7 +2036,7 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   }
   const int np = (int)h->np;
   const int64_t ld = h->np;
-  const int tile = (int)std::min<int64_t>(PRED_TILE, round_up(ns, NB));
+  const int tile = (int)std::min<int64_t>(pred_tile_for(h->np), round_up(ns, NB));
   // Many test points: V = L^-1 Ks as ONE triangular GEMM per tile against the explicit inverse (computed once
   // per factorisation, N^3/3 flops amortised over N* >= 2 N points) instead of the recursive solve's ~2 N/64
   // dependent launches per tile.  Few points: blocked forward substitution on L itself.
