@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: rocprofv3 kernel stats of the other sizes of the target (one matrix at N = 4096 with both schedules, N = 16384; many
+# Round 4: rocprofv3 kernel stats of the other sizes of the target (one matrix at N = 4096 with both schedules, N = 16384; many
 # cells at N = 1024 and at N = 512 with both batched schedules).  On the GPU box: bash tools/prof_sizes_r3.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # tag, env assignment, command...
@@ -10,9 +10,8 @@ run() {  # tag, env assignment, command...
   cp $(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
   echo "== $tag: $(tail -1 gpurun_out/${tag}.log)"; cut -c1-150 gpurun_out/${tag}_kernel_stats.csv | head -7
 }
-run r03_n4096_single GPRX_X=0 python3 tools/large_probe.py 4096 8
-run r03_n4096_single_tile_dag GPRX_DAG=1 python3 tools/large_probe.py 4096 8
-run r03_n16384_single GPRX_X=0 python3 tools/large_probe.py 16384 12
-run r03_n1024_batched GPRX_CELL_KERNEL=-1 python3 tools/batch_n1024.py 1024 512
-run r03_n1024_batched_cell_kernel GPRX_CELL_KERNEL=1 python3 tools/batch_n1024.py 1024 512
-run r03_n512_batched_cell_kernel GPRX_X=0 python3 tools/batch_n1024.py 512 512
+run r04_n4096_single GPRX_X=0 python3 tools/large_probe.py 4096 8
+run r04_n8192_single GPRX_X=0 python3 tools/large_probe.py 8192 8
+run r04_n1024_batched GPRX_CELL_KERNEL=-1 python3 tools/batch_n1024.py 1024 512
+run r04_n512_batched_cell_kernel GPRX_X=0 python3 tools/batch_n1024.py 512 512
+run r04_f2_batched GPRX_X=0 python3 tools/f2_prof.py 128
