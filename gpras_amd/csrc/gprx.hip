@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "comm.h"
@@ -94,6 +96,9 @@ struct gprx_ctx {
   Buf apart;                                      // row-chunk partial sums of alpha_from_inverse
   hipEvent_t kev[2] = {nullptr, nullptr};         // profiling: events around the kernel-build launch
   double kmat_ms = 0.0, kmat_bytes = 0.0;
+  std::vector<Theta> batch_thetas;                // gprx_factorize_batch: decoded parameter sets of the last call (buffers reused)
+  std::vector<double> batch_lml;
+  hipEvent_t wev = nullptr;                       // completion event of wait_stream
   hipEvent_t cev[2] = {nullptr, nullptr};         // profiling: events around the one-workgroup-per-cell kernel's launch
   bool cev_recorded = false;
   double cell_ms = 0.0, cell_flops = 0.0, cell_cells = 0.0;
@@ -245,16 +250,50 @@ __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(double* out, int ite
   if (s.x == 123.456) out[0] = s.y;
 }
 
-Theta decode_theta(gprx_handle h, const double* theta) {
-  Theta t;
+void decode_theta_into(gprx_handle h, const double* theta, Theta& t) {
   t.w_var = theta[0];
   t.w_noise = theta[1 + h->nlen];
   t.variance = softplus(t.w_var);
   t.noise = NOISE_LOWER + softplus(t.w_noise);
   t.w_len.assign(theta + 1, theta + 1 + h->nlen);
   t.ls.resize(h->d);
-  for (int k = 0; k < h->d; ++k) t.ls[k] = softplus(t.w_len[h->ard ? k : 0]);
+  if (h->ard) {
+    for (int k = 0; k < h->d; ++k) t.ls[k] = softplus(t.w_len[k]);
+  } else {
+    const double l = softplus(t.w_len[0]);  // (one shared lengthscale: one softplus, not d)
+    for (int k = 0; k < h->d; ++k) t.ls[k] = l;
+  }
+}
+Theta decode_theta(gprx_handle h, const double* theta) {
+  Theta t;
+  decode_theta_into(h, theta, t);
   return t;
+}
+
+// Wait for everything enqueued on `st`.  hipStreamSynchronize blocks in the driver and returns 60-100 us after the GPU has finished
+// (tools/batch_overhead.py: 150 us of host time around a 1.1 ms batch of 512 cells of N = 512 -- 12 % of the call, 3 % at N = 1024, 4 % of a
+// lone N = 4096 fit); a completion event polled from the calling thread returns within a few us.  Pure spinning for the first 2 ms, then the
+// poll yields the core between queries, and after 200 ms (the long batched steps, where the wake-up latency is noise) it hands over to
+// hipStreamSynchronize.  GPRX_WAIT_BLOCKING=1 restores the blocking wait.
+hipError_t wait_stream(gprx_handle h, hipStream_t st) {
+  static const bool blocking = getenv("GPRX_WAIT_BLOCKING") && atoi(getenv("GPRX_WAIT_BLOCKING")) != 0;
+  if (blocking) return hipStreamSynchronize(st);
+  if (!h->wev) {
+    hipError_t e = hipEventCreateWithFlags(&h->wev, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(h->wev, st);
+  if (e != hipSuccess) return e;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    e = hipEventQuery(h->wev);
+    if (e != hipErrorNotReady) return e;
+    if ((spins & 63) == 63) {
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (us > 200000.0) return hipStreamSynchronize(st);
+      if (us > 2000.0) std::this_thread::yield();
+    }
+  }
 }
 
 double log_prior(gprx_handle h, const Theta& t, int mask) {
@@ -471,7 +510,7 @@ void summarize_profile(gprx_handle h) {
 }
 
 int exact_factorize_finish(gprx_handle h, double* lml_out) {
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h, h->stream));
   const double* red = h->pin + 64;
   int info = 0;
   std::memcpy(&info, h->pin + 72, sizeof(int));
@@ -688,7 +727,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
   }
   HIPCHK(h, hipMemcpyAsync(res, h->cellres.p, sizeof(double) * CELL_RES * count, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipEventRecord(h->bev[1], st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(h, st));
   float ms = 0.f;
   hipEventElapsedTime(&ms, h->bev[0], h->bev[1]);
   h->batch_ms = ms;
@@ -810,7 +849,7 @@ int exact_gradient_batch(gprx_handle h, int count, double* g, bool form_alpha = 
   hipLaunchKernelGGL(trace_final, dim3(width, count), dim3(64), 0, st, (const double*)h->gpartial.p, tiles * tiles, width, sums0, ps);
   std::vector<double> host((size_t)width * count);
   HIPCHK(h, hipMemcpyAsync(host.data(), sums0, sizeof(double) * width * count, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(h, st));
   for (int c = 0; c < count; ++c) {
     if (!h->slot_ok[c]) continue;
     const double* hs = host.data() + (size_t)c * width;
@@ -880,7 +919,7 @@ int exact_gradient(gprx_handle h, const Theta& t, double* g) {
   std::vector<double> host(2 + h->d);
   int rc;
   if ((rc = exact_gradient_enqueue(h, t, host.data(), false))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h, h->stream));
   exact_gradient_collect(h, host.data(), g);
   return GPRX_OK;
 }
@@ -962,7 +1001,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   int info = 0;
   HIPCHK(h, hipMemcpyAsync(red, h->red.p, sizeof(red), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(h, st));
   if (info != 0) {
     h->factorized = false;
     char msg[128];
@@ -1045,7 +1084,7 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   HIPCHK(h, hipMemcpyAsync(hs.data(), sums, sizeof(double) * 2 * width, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(red, h->red.p, sizeof(red), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(hz.data(), h->dZ.p, sizeof(double) * m * d, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(h, st));
   const double nn = (double)h->n;
   const double tr_sinv_pp = s * ((double)mp - red[3]);
   const double tr_qinv_pp = s * h->elbo_trAAT;
@@ -1371,7 +1410,7 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   const double* hred = h->spin + sg.red;
   const double* hsum = h->spin + sg.sum;
   const double* hdz = h->spin + sg.dz;
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(h, st));
   h->factorized = false;  // the single-model state of the handle is untouched but no longer "the last evaluation"
   int first_error = GPRX_OK;
   const double nn = (double)h->n;
@@ -1541,6 +1580,7 @@ int gprx_destroy(gprx_handle h) {
     if (ev) hipEventDestroy(ev);
   for (auto& ev : h->cev)
     if (ev) hipEventDestroy(ev);
+  if (h->wev) hipEventDestroy(h->wev);
   if (h->info) hipFree(h->info);
   if (h->pin) hipHostFree(h->pin);
   if (h->gparams) hipFree(h->gparams);
@@ -1584,7 +1624,7 @@ int gprx_set_distance_form(gprx_handle h, int form) {
 int gprx_synchronize(gprx_handle h) {
   int rc;
   if ((rc = check_handle(h))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h, h->stream));
   return GPRX_OK;
 }
 
@@ -1676,7 +1716,7 @@ static int objective_impl(gprx_handle h, int unit, const double* theta, const do
   } else {
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
   }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h, h->stream));
   for (int s = 0; s < 4; ++s) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, h->ev[s], h->ev[s + 1]);
@@ -1796,14 +1836,18 @@ int gprx_factorize_batch(gprx_handle h, int count, const int* units, const doubl
   if (count <= 0 || !units || !thetas) return fail(h, GPRX_EINVAL, "count must be positive, units and thetas non-null");
   if (h->m != 0) return fail(h, GPRX_EINVAL, "gprx_factorize_batch: exact models only");
   if (h->d > CELL_PAR - CELL_PAR_LS) return fail(h, GPRX_EINVAL, "gprx_factorize_batch: d <= 64 only");
-  std::vector<Theta> ts(count);
+  // (the handle keeps the decoded parameter sets of the last batch: their lengthscale vectors are reused, no allocation per cell and call --
+  // 512 cells of N = 512 spent 68 us here, 5 % of the call)
+  std::vector<Theta>& ts = h->batch_thetas;
+  if ((int)ts.size() < count) ts.resize(count);
   for (int i = 0; i < count; ++i) {
     if (units[i] < 0 || units[i] >= h->n_units) return fail(h, GPRX_EINVAL, "unit out of range (call gprx_set_data first)");
     for (int k = 0; k < h->ntheta; ++k)
       if (!std::isfinite(thetas[(int64_t)i * h->ntheta + k])) return fail(h, GPRX_EINVAL, "theta is not finite");
-    ts[i] = decode_theta(h, thetas + (int64_t)i * h->ntheta);
+    decode_theta_into(h, thetas + (int64_t)i * h->ntheta, ts[i]);
   }
-  std::vector<double> lml(count);
+  std::vector<double>& lml = h->batch_lml;
+  if ((int)lml.size() < count) lml.resize(count);
   rc = exact_factorize_batch(h, count, units, ts.data(), lml.data(), status);
   if (rc != GPRX_OK && rc != GPRX_ENOTPD) return rc;
   if (losses)
@@ -2091,7 +2135,7 @@ int gprx_predict(gprx_handle h, const double* xs, int64_t ns, double* mean, doub
   if ((rc = gprx_predict_dev(h, dxs, ns, dmean, dvar, include_noise))) return rc;
   HIPCHK(h, hipMemcpyAsync(mean, dmean, sizeof(double) * ns, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(var, dvar, sizeof(double) * ns, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h, h->stream));
   return GPRX_OK;
 }
 
@@ -2192,7 +2236,7 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
       HIPCHK(h, hipMemcpyAsync(means + (int64_t)c0 * ns, dmean, sizeof(double) * ns * cnt, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipMemcpyAsync(vars + (int64_t)c0 * ns, dvar, sizeof(double) * ns * cnt, hipMemcpyDeviceToHost, h->stream));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h, h->stream));
   }
   return GPRX_OK;
 }
