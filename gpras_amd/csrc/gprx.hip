@@ -3037,6 +3037,16 @@ int gprx_panel_acc(unsigned long long* out8, int reset) {
   return 0;
 }
 #endif
+#ifdef GPRX_CELL_ACC
+int gprx_cell_acc(unsigned long long* out16, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(gprx::g_cell_acc), z, sizeof(z));
+  }
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(gprx::g_cell_acc), sizeof(unsigned long long) * 16);
+  return 0;
+}
+#endif
 #ifdef GPRX_PANEL_STAMPS
 int gprx_panel_stamps(unsigned long long* out64) {
   hipMemcpyFromSymbol(out64, HIP_SYMBOL(gprx::g_panel_stamps), sizeof(unsigned long long) * 64);

@@ -45,6 +45,25 @@ __device__ __forceinline__ int cell_tid() {
   return t;
 }
 
+// GPRX_CELL_ACC (development builds, tools/cell_acc.sh): phase durations of workgroup 0 of potrf_cell2_kernel in s_memrealtime ticks
+// (100 MHz), summed over launches: [0] launches, [1] the diagonal pair's streaming product, [2] the rest of the diagonal pair (tile
+// fetches, the two chains, the solve between them), [3] the beta steps, [4] a row group's streaming product, [5] E1, [6] E2, [7] E3.
+#ifdef GPRX_CELL_ACC
+__device__ unsigned long long g_cell_acc[16];
+#define CACC(i)                                                                  \
+  {                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                   \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();            \
+      if ((i) > 0) atomicAdd(&g_cell_acc[i], t_ - s_cacc_prev);                  \
+      else atomicAdd(&g_cell_acc[0], 1ull);                                      \
+      s_cacc_prev = t_;                                                          \
+    }                                                                            \
+  }
+__shared__ unsigned long long s_cacc_prev;
+#else
+#define CACC(i)
+#endif
+
 struct CellArgs {
   double* A;         // cell 0; cells are `cs` doubles apart
   int64_t lda;
@@ -704,6 +723,7 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, cons
       cell2_zero(acc[t][c]);
     }
   cell2_stream<NI, false>(acc, p.A + (int64_t)i0 * NB * p.lda, p.A + (int64_t)j * NB * p.lda, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r);
+  CACC(4)
   // ---- the solve steps: one B image at a time (L(j,j)^-1, then L(j+1,j), then L(j+1,j+1)^-1), every row tile against it ----
   // (the streaming loop's last barrier has passed: both stage buffers are free)
   double* sA = smem;
@@ -721,6 +741,7 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, cons
     cell2_store(acc[t][0], tile(i0 + t, j), q);
     lds_barrier();  // the A image is free again
   }
+  CACC(5)
   // E2: acc(t, 1) += L(i, j) L(j + 1, j)^T
   cell2_dma_block(tile(j + 1, j), p.lda, sB, wave_u, lane);
 #pragma unroll
@@ -730,6 +751,7 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, cons
     dag_mma64(acc[t][1], sA, sB, q.wm, q.wn, q.g, q.r, swz);
     lds_barrier();
   }
+  CACC(6)
   // E3: L(i, j + 1) = (A(i, j + 1) - acc(t, 1)) L(j + 1, j + 1)^-T
   cell2_dma_block(p.inv_diag + (int64_t)(j + 1) * NB * NB, NB, sB, wave_u, lane);
 #pragma unroll
@@ -742,6 +764,7 @@ __device__ __forceinline__ void cell2_rows(const TileCtx& p, int i0, int j, cons
     cell2_store(acc[t][1], tile(i0 + t, j + 1), q);
     lds_barrier();
   }
+  CACC(7)
 }
 
 // The pair's own three tiles (j, j), (j + 1, j), (j + 1, j + 1): ONE streaming product of the 128-row panel with itself (what the
@@ -770,6 +793,7 @@ __device__ __forceinline__ int cell2_diag_pair(const TileCtx& p, int j, const Ce
   } else {
     cell2_stream<2, true>(acc, Prow, Prow, p.lda, j * NB, smem, lane, wave_u, q.wm, q.wn, q.g, q.r);
   }
+  CACC(1)
   auto tile = [&](int i, int jc) { return p.A + (int64_t)i * NB * p.lda + (int64_t)jc * NB; };
   double* inv = const_cast<double*>(p.inv_diag);
   double* sA = smem;
@@ -814,6 +838,7 @@ __global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellAr
   const Cell2Beta bq{BETA ? p.beta + off : nullptr, sbeta, sbeta + CELL2_BETA_MAXT * NB, sbeta + CELL2_BETA_MAXT * NB + 256, sbeta + CELL2_BETA_MAXT * NB + 512};
   if (KB) exp_tab_fill(smem + CELL2_KX + 64 * KM_DC + KM_DC * KM_BT_LD);  // (visible after the first barrier of the first tile's staging)
   int first_bad = 0;
+  CACC(0)
   for (int j = 0; j < p.T; j += 2) {
     if (j + 1 >= p.T) {  // a last single column: the single-column passes
       if (j > 0) {
@@ -833,7 +858,9 @@ __global__ __launch_bounds__(256, GPRX_CELL2_OCC) void potrf_cell2_kernel(CellAr
     const int bad = cell2_diag_pair<KB, BETA>(tc, j, kq, smem, &bq);
     if (bad > 0 && first_bad == 0) first_bad = j * NB + bad;
     cell_sync();
+    CACC(2)
     if constexpr (BETA) cell2_beta_pair(tc, j, bq, cell_tid());
+    CACC(3)
 #ifndef GPRX_CELL2_NOROWS
     int i0 = j + 2;
     for (; i0 + 1 < p.R; i0 += 2) {
