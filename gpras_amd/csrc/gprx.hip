@@ -94,6 +94,7 @@ struct gprx_ctx {
   // [K (np + 64) x np | invD np x 64 | staged diagonal blocks np x 128 | alpha np]; parameter / result tables, one row per cell
   Buf arena, cellpar, cellres, garena, gpartial;  // garena: per cell [L^-1 | K^-1] for batched gradients
   Buf apart;                                      // row-chunk partial sums of alpha_from_inverse
+  Buf twork;                                      // work vector of the lone backward solve (np doubles)
   hipEvent_t kev[2] = {nullptr, nullptr};         // profiling: events around the kernel-build launch
   double kmat_ms = 0.0, kmat_bytes = 0.0;
   std::vector<Theta> batch_thetas;                // gprx_factorize_batch: decoded parameter sets of the last call (buffers reused)
@@ -356,6 +357,7 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   if ((rc = ensure(h, h->Kmat, sizeof(double) * (h->np + NB) * ld))) return rc;
   if ((rc = ensure(h, h->invD, sizeof(double) * h->np * NB))) return rc;
   if ((rc = ensure(h, h->alpha, sizeof(double) * h->np))) return rc;
+  if ((rc = ensure(h, h->twork, sizeof(double) * h->np))) return rc;
   if ((rc = ensure(h, h->dstage, sizeof(double) * h->np * STAGE_LD))) return rc;
   if (lookahead && (rc = ensure_lookahead(h))) return rc;
   if (h->Kmat.borrowed && h->arena.p && h->cell_stride > 0) {
@@ -405,9 +407,10 @@ int exact_factorize_enqueue(gprx_handle h, int unit, const Theta& t, bool lookah
   }
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[2], st));
   const double* beta = h->Kmat.p + (int64_t)np * ld;
-  if (with_alpha) hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->alpha.p, np);
+  // (alpha = L^-T beta: beta is copied into a work vector that the solve uses up, alpha receives the solution -- two block steps per launch)
+  if (with_alpha) hipLaunchKernelGGL(copy_row_kernel, dim3((np + 255) / 256), dim3(256), 0, st, beta, h->twork.p, np);
   hipLaunchKernelGGL(logdet_quad_kernel, dim3(1), dim3(256), 0, st, (const double*)h->Kmat.p, ld, beta, np, h->red.p, (int64_t)0, 0);
-  if (with_alpha) HIPCHK(h, trsv_lower(st, h->Kmat.p, ld, h->invD.p, h->alpha.p, np, true));
+  if (with_alpha) HIPCHK(h, trsv_lower(st, h->Kmat.p, ld, h->invD.p, h->alpha.p, np, true, 1, 0, h->twork.p));
   if (!capture) HIPCHK(h, hipEventRecord(h->ev[3], st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 64, h->red.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(h->pin + 72, h->info, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1569,7 +1572,7 @@ int gprx_destroy(gprx_handle h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Buf* b : {&h->X, &h->Y, &h->Z, &h->invls, &h->alpha, &h->red, &h->Kmat, &h->invD, &h->Xinv, &h->Tmp, &h->partial, &h->xs, &h->Ks,
                  &h->pred, &h->P, &h->Am, &h->Qm, &h->Bm, &h->invDL, &h->invDB, &h->SM, &h->WP, &h->WHP, &h->WHQ, &h->vecs, &h->dZ,
-                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial, &h->apart, &h->sarena})
+                 &h->dstage, &h->splitws, &h->arena, &h->cellpar, &h->cellres, &h->garena, &h->gpartial, &h->apart, &h->twork, &h->sarena})
     if (b->p && !b->borrowed) hipFree(b->p);
   if (h->bpin) hipHostFree(h->bpin);
   if (h->spin) hipHostFree(h->spin);

@@ -60,20 +60,22 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ 
 //                                                   thread in flight at once, then an LDS reduction)
 //   workgroup j == i - 1 then forms x_{i-1} = invD_{i-1}^T b_{i-1}.
 // Step i == nblocks only forms x_{nblocks-1}.
+// x: where the solution blocks live -- b itself (in place, the default: xsep == nullptr) or a separate vector (trsv_bwd_pair_step below)
 __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
-                                                     double* __restrict__ b, int i, int nblocks, int64_t cs) {
+                                                     double* b, int i, int nblocks, int64_t cs, double* xsep = nullptr) {
   __shared__ double sx[NB];
   __shared__ double sb[NB];
   __shared__ double part[4][NB];
   L += (int64_t)blockIdx.y * cs;
   inv_diag += (int64_t)blockIdx.y * cs;
   b += (int64_t)blockIdx.y * cs;
+  double* x = xsep ? xsep : b;
   const int tid = threadIdx.x;
   const int t = tid & 63, grp = tid >> 6;
   const int j = i - 1 - (int)blockIdx.x;
   if (j < 0) return;
   if (i < nblocks) {
-    if (tid < NB) sx[tid] = b[i * NB + tid];
+    if (tid < NB) sx[tid] = x[i * NB + tid];
     const double* lp = L + (int64_t)(i * NB + grp * 16) * lda + j * NB + t;
     double lv[16];
 #pragma unroll
@@ -104,7 +106,91 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ 
   }
   part[grp][t] = s;
   __syncthreads();
-  if (tid < NB) b[j * NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  if (tid < NB) x[j * NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
+
+// TWO block steps of the backward solve in one launch, for ONE system (a lone fit's alpha = L^-T beta is a chain of N / 64 dependent
+// launches of ~4 us each: 0.26 ms of a 2.5 ms fit at N = 4096).  On entry x_i is final and w_j (j < i) holds beta_j minus what the blocks
+// above i contribute; workgroup j (j = i - 2 ... 0) forms x_{i-1} = invD_{i-1}^T (w_{i-1} - L(i, i-1)^T x_i) ITSELF -- two extra 64 x 64
+// tiles from L2 per workgroup instead of a launch boundary --, then w_j -= L(i, j)^T x_i, w_j -= L(i-1, j)^T x_{i-1}, and workgroup i - 2
+// goes on to x_{i-2}.  Every sum is the one trsv_bwd_step forms, in its order: the solution is the same bit for bit (tested).  x and w
+// are separate vectors (everybody reads w_{i-1} while x_{i-1} is being written).
+__global__ __launch_bounds__(256) void trsv_bwd_pair_step(const double* __restrict__ L, int64_t lda, const double* __restrict__ inv_diag,
+                                                          double* __restrict__ w, double* __restrict__ x, int i) {
+  __shared__ double sx[NB];    // x_i
+  __shared__ double sx1[NB];   // x_{i-1}
+  __shared__ double sb[NB];
+  __shared__ double part[4][NB];
+  const int tid = threadIdx.x;
+  const int t = tid & 63, grp = tid >> 6;
+  const int j = i - 2 - (int)blockIdx.x;
+  if (j < 0) return;
+  // every load up front: the own tiles of block rows i and i - 1, and what x_{i-1} needs
+  const double* lp_i = L + (int64_t)(i * NB + grp * 16) * lda + j * NB + t;
+  const double* lp_1 = L + (int64_t)((i - 1) * NB + grp * 16) * lda + j * NB + t;
+  const double* lp_d = L + (int64_t)(i * NB + grp * 16) * lda + (i - 1) * NB + t;
+  const double* ip = inv_diag + (int64_t)(i - 1) * NB * NB;
+  const double* ip2 = inv_diag + (int64_t)j * NB * NB;  // (used by workgroup i - 2 only; everybody loads: uniform code, L2-resident lines)
+  double li[16], l1[16], ld_[16], iv[16], iv2[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    li[m] = lp_i[(int64_t)m * lda];
+    l1[m] = lp_1[(int64_t)m * lda];
+    ld_[m] = lp_d[(int64_t)m * lda];
+    iv[m] = ip[(grp * 16 + m) * NB + t];
+    iv2[m] = ip2[(grp * 16 + m) * NB + t];
+  }
+  const double w_i1 = w[(i - 1) * NB + t], w_j = w[j * NB + t];  // (every memory round trip of the launch is in flight now)
+  if (tid < NB) sx[tid] = x[i * NB + tid];
+  __syncthreads();
+  // w_{i-1} - L(i, i-1)^T x_i  (what workgroup i - 1 of trsv_bwd_step(i) computes)
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) s = __builtin_fma(ld_[m], sx[grp * 16 + m], s);
+  part[grp][t] = s;
+  __syncthreads();
+  if (tid < NB) sb[tid] = w_i1 - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+  __syncthreads();
+  // x_{i-1} = invD_{i-1}^T (that)
+  s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) s = __builtin_fma(iv[m], sb[grp * 16 + m], s);
+  part[grp][t] = s;
+  __syncthreads();
+  if (tid < NB) {
+    const double v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    sx1[tid] = v;
+    if (blockIdx.x == 0) x[(i - 1) * NB + tid] = v;
+  }
+  __syncthreads();
+  // own block: the two updates, one after the other (two roundings, as the two launches made them)
+  s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) s = __builtin_fma(li[m], sx[grp * 16 + m], s);
+  part[grp][t] = s;
+  __syncthreads();
+  double v1 = 0.0;
+  if (tid < NB) v1 = w_j - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+  __syncthreads();
+  s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) s = __builtin_fma(l1[m], sx1[grp * 16 + m], s);
+  part[grp][t] = s;
+  __syncthreads();
+  if (tid < NB) {
+    const double v2 = v1 - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+    w[j * NB + tid] = v2;
+    sb[tid] = v2;
+  }
+  if (j != i - 2) return;
+  __syncthreads();
+  // x_{i-2} = invD_{i-2}^T w_{i-2}
+  s = 0.0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) s = __builtin_fma(iv2[m], sb[grp * 16 + m], s);
+  part[grp][t] = s;
+  __syncthreads();
+  if (tid < NB) x[j * NB + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
 // ---- alpha = L^-T beta from the explicit inverse X = L^-1 (the gradient has just built it): alpha_j = sum_{i >= j} X[i][j] beta_i.
@@ -150,9 +236,19 @@ inline hipError_t alpha_from_inverse(hipStream_t st, const double* X, int64_t ld
   return hipGetLastError();
 }
 
+// work (transpose, ONE system only): a vector that holds the right-hand side on entry and is used up; b then only receives the solution,
+// and the block steps run two per launch (trsv_bwd_pair_step).  GPRX_TRSV_PAIR=0 falls back to one step per launch on the same two vectors.
 inline hipError_t trsv_lower(hipStream_t st, const double* L, int64_t lda, const double* inv_diag, double* b, int np, bool transpose,
-                             int batch = 1, int64_t cs = 0) {
+                             int batch = 1, int64_t cs = 0, double* work = nullptr) {
   const int nblocks = np / NB;
+  if (transpose && work && batch == 1) {
+    static const bool pair = !(getenv("GPRX_TRSV_PAIR") && atoi(getenv("GPRX_TRSV_PAIR")) == 0);
+    hipLaunchKernelGGL(trsv_bwd_step, dim3(1, 1), dim3(256), 0, st, L, lda, inv_diag, work, nblocks, nblocks, (int64_t)0, b);
+    int i = nblocks - 1;
+    for (; pair && i >= 2; i -= 2) hipLaunchKernelGGL(trsv_bwd_pair_step, dim3(i - 1), dim3(256), 0, st, L, lda, inv_diag, work, b, i);
+    for (; i >= 1; --i) hipLaunchKernelGGL(trsv_bwd_step, dim3(i, 1), dim3(256), 0, st, L, lda, inv_diag, work, i, nblocks, (int64_t)0, b);
+    return hipGetLastError();
+  }
   if (!transpose) {
     for (int i = -1; i < nblocks - 1; ++i)
       hipLaunchKernelGGL(trsv_fwd_step, dim3(i < 0 ? 1 : nblocks - 1 - i, batch), dim3(256), 0, st, L, lda, inv_diag, b, i, nblocks, cs);

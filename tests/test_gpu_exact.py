@@ -334,3 +334,48 @@ def test_alpha_from_the_gradients_inverse_agrees_with_backward_substitution(lib,
         assert np.max(np.abs(m1 - ref_mean)) <= 1e-8 * np.max(np.abs(ref_mean))
     finally:
         lib.gprx_destroy(h)
+
+
+PAIR_SOLVE = r"""
+import ctypes as C, json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from gpras_amd import _lib
+from gpras_amd._lib import check, ptr
+from gpras_amd.synth import make_regression
+from oracle import transforms as otr
+lib = _lib.load()
+out = []
+for n, d in ((50, 2), (128, 3), (190, 2), (448, 4), (1000, 5), (2100, 8)):  # 1, 2, 3, 7, 16 and 33 block steps
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=40, config=3, unit=n)
+    theta = np.array(otr.unconstrain(1.3, float(np.mean(np.abs(x))), 0.2), dtype=np.float64)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, 0, 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    loss = C.c_double()
+    check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss)), h)
+    mean, var = np.zeros(40), np.zeros(40)
+    check(lib.gprx_predict(h, ptr(xs), 40, ptr(mean), ptr(var), 1), h)
+    lib.gprx_destroy(h)
+    out += [float.hex(v) for v in mean] + [float.hex(loss.value)]
+print(json.dumps(out))
+"""
+
+
+def test_backward_solve_two_steps_per_launch_equals_one_step_per_launch_bit_for_bit():
+    """A lone fit's alpha = L^-T beta runs two block steps per launch (trsv_bwd_pair_step: every workgroup forms x_{i-1} itself instead
+    of waiting for a launch boundary).  Every sum is the one-step kernel's, in its order: the predictive means (K*^T alpha) of six sizes
+    -- odd and even block counts, one block, two blocks -- are the same bits with GPRX_TRSV_PAIR=0, and they match the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"GPRX_TRSV_PAIR": "0"}, {}):
+        base = {k: v for k, v in os.environ.items() if k != "GPRX_TRSV_PAIR"}
+        res = subprocess.run([sys.executable, "-c", PAIR_SOLVE.format(root=root)], capture_output=True, text=True, timeout=600, env=dict(base, **env))
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
