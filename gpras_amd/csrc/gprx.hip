@@ -288,7 +288,12 @@ hipError_t wait_stream(gprx_handle h, hipStream_t st) {
   const auto t0 = std::chrono::steady_clock::now();
   for (int spins = 0;; ++spins) {
     e = hipEventQuery(h->wev);
-    if (e != hipErrorNotReady) return e;
+    if (e != hipErrorNotReady) {
+      // (a poll that found the event pending may have left hipErrorNotReady behind as the thread's "last error": the launch helpers end
+      // with hipGetLastError() and must not trip over it)
+      if (spins > 0) (void)hipGetLastError();
+      return e;
+    }
     if ((spins & 63) == 63) {
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       if (us > 200000.0) return hipStreamSynchronize(st);
