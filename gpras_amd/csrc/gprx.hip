@@ -1070,9 +1070,13 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
   double* partP = h->partial.p;
   double* partQ = partP + part_p;
   double* sums = partQ + part_q;
+  // (one shared lengthscale -- the reference's default kernels: the per-dimension pass collapses to one FMA per element, round 4 for the
+  // sparse model too: sum_k ds_k^2 is the r2 of the first pass whatever d is and whether or not w v h is stored for dz_kernel)
   TraceArgs tp{h->Z.p, h->X.p, h->invls.p, h->WP.p, np, mvec, yu, 1.0 / s, 1.0 / s, m, n, d, t.variance, 0, partP, h->WHP.p, np, tiles_n};
+  tp.iso = h->ard ? 0 : 1;
   HIPCHK(h, launch_trace(st, h->kid, with_form(tp, h), tiles_m * tiles_n));
   TraceArgs tq{h->Z.p, h->Z.p, h->invls.p, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, t.variance, 0, partQ, h->WHQ.p, mp, tiles_m};
+  tq.iso = h->ard ? 0 : 1;
   HIPCHK(h, launch_trace(st, h->kid, with_form(tq, h), tiles_m * tiles_m));
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partP, tiles_m * tiles_n, width, sums);
   hipLaunchKernelGGL(trace_final, dim3(width), dim3(64), 0, st, (const double*)partQ, tiles_m * tiles_m, width, sums + width);
@@ -1317,6 +1321,7 @@ int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_
     tp.a_stride = ss;
     tp.wh_stride = ss;
     tp.scale_inv_noise = 1;
+    tp.iso = h->ard ? 0 : 1;
     TraceArgs tq{A0 + L.oZ, A0 + L.oZ, nullptr, GQ, mp, nullptr, nullptr, 1.0, 0.0, m, m, d, 0.0, 0, partQ, A0 + L.oWHQ, mp, tiles_m};
     tq.cell_par = cpar;
     tq.w_stride = ss;
@@ -1324,6 +1329,7 @@ int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_
     tq.a_stride = ss;
     tq.b_stride = ss;
     tq.wh_stride = ss;
+    tq.iso = h->ard ? 0 : 1;
     HIPCHK(h, launch_trace_pair(st, h->kid, with_form(tp, h), tiles_m * tiles_n, with_form(tq, h), tiles_m * tiles_m, count));
     HIPCHK(h, launch_gemm(st, 1, 0, np, 1, mp, 1.0, A0 + L.oP, np, mvec, 1, 0.0, qvec, 1, 0, 64, 1, 0, 0, 0, count, ss, ss, ss));
     hipLaunchKernelGGL(resid_sumsq_kernel, dim3(1, count), dim3(256), 0, st, (const double*)(A0 + L.oY), (const double*)qvec, n, A0 + L.oRed + 4, ss,

@@ -37,7 +37,7 @@ struct TraceArgs {
   int64_t a_stride = 0, b_stride = 0, v_stride = -1, wh_stride = 0;  // v_stride < 0: v advances like u
   int scale_inv_noise = 0;  // 1: w_scale = uv_scale = 1 / table[1] (the sparse model's 1 / s)
   int form = 0;             // distance form of r2 inside g and h (kmat.h); the factors ds_k of the derivatives stay differences
-  int iso = 0;              // 1: ONE lengthscale for every dimension (the reference's default kernels): only the sum over k of the
+  int iso = 0;              // 1: ONE lengthscale for every dimension (the reference's default kernels; any d, with or without wh_out): only the sum over k of the
                             // lengthscale traces is wanted -- partial[wg][2] = -sum w v h r2 / l, partial[wg][3 ..] = 0
 };
 
@@ -275,15 +275,15 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs p) {  // (216 VGPR
   trace_body<KID, FORM, ISO>(p, (int)blockIdx.x, sA, sBt, sRed);
 }
 // Two contractions in one launch (the sparse model's Kuf and Kuu terms): workgroups [0, first) take p, the rest q.
-template <int KID, int FORM = 0>
+template <int KID, int FORM = 0, int ISO = 0>
 __global__ __launch_bounds__(256) void trace_pair_kernel(TraceArgs p, TraceArgs q, int first) {
   __shared__ __attribute__((aligned(16))) double sA[KM_T][KM_DC];
   __shared__ __attribute__((aligned(16))) double sBt[KM_DC][KM_T];
   __shared__ double sRed[4][KM_DC + 2];
   if ((int)blockIdx.x < first)
-    trace_body<KID, FORM>(p, (int)blockIdx.x, sA, sBt, sRed);
+    trace_body<KID, FORM, ISO>(p, (int)blockIdx.x, sA, sBt, sRed);
   else
-    trace_body<KID, FORM>(q, (int)blockIdx.x - first, sA, sBt, sRed);
+    trace_body<KID, FORM, ISO>(q, (int)blockIdx.x - first, sA, sBt, sRed);
 }
 
 // dELBO/dZ of the sparse model:
@@ -396,7 +396,7 @@ inline hipError_t launch_trace(hipStream_t st, int kid, TraceArgs p, int grid, i
   case K_:                                                                    \
     if (p.form)                                                               \
       hipLaunchKernelGGL((trace_kernel<K_, 1>), g, b, 0, st, p);              \
-    else if (p.iso && !p.wh_out && p.d <= KM_DC)                              \
+    else if (p.iso)                                                           \
       hipLaunchKernelGGL((trace_kernel<K_, 0, 1>), g, b, 0, st, p);           \
     else                                                                      \
       hipLaunchKernelGGL((trace_kernel<K_, 0>), g, b, 0, st, p);              \
@@ -420,6 +420,8 @@ inline hipError_t launch_trace_pair(hipStream_t st, int kid, TraceArgs p, int gr
   case K_:                                                                                 \
     if (p.form)                                                                            \
       hipLaunchKernelGGL((trace_pair_kernel<K_, 1>), g, b, 0, st, p, q, grid_p);           \
+    else if (p.iso && q.iso)                                                               \
+      hipLaunchKernelGGL((trace_pair_kernel<K_, 0, 1>), g, b, 0, st, p, q, grid_p);        \
     else                                                                                   \
       hipLaunchKernelGGL((trace_pair_kernel<K_, 0>), g, b, 0, st, p, q, grid_p);           \
     break;
