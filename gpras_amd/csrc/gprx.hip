@@ -276,6 +276,10 @@ Theta decode_theta(gprx_handle h, const double* theta) {
 // lone N = 4096 fit); a completion event polled from the calling thread returns within a few us.  Pure spinning for the first 2 ms, then the
 // poll yields the core between queries, and after 200 ms (the long batched steps, where the wake-up latency is noise) it hands over to
 // hipStreamSynchronize.  GPRX_WAIT_BLOCKING=1 restores the blocking wait.
+int& wait_handover_us() {
+  static int v = 200000;  // gprx_set_tuning("wait_handover_us", ...): tests lower it to 0 to force the hand-over path
+  return v;
+}
 hipError_t wait_stream(gprx_handle h, hipStream_t st) {
   static const bool blocking = getenv("GPRX_WAIT_BLOCKING") && atoi(getenv("GPRX_WAIT_BLOCKING")) != 0;
   if (blocking) return hipStreamSynchronize(st);
@@ -296,7 +300,12 @@ hipError_t wait_stream(gprx_handle h, hipStream_t st) {
     }
     if ((spins & 63) == 63) {
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      if (us > 200000.0) return hipStreamSynchronize(st);
+      if (us > (double)wait_handover_us()) {
+        // (the polls above left hipErrorNotReady as the thread's last error -- it is sticky across later successful calls on
+        // this runtime -- and the next launch helper ending in hipGetLastError() would report it for a good call)
+        (void)hipGetLastError();
+        return hipStreamSynchronize(st);
+      }
       if (us > 2000.0) std::this_thread::yield();
     }
   }
@@ -3089,6 +3098,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "split_updates" && value >= 0 && value <= 1) t.split_updates = value;
   else if (k == "poison_workspace" && value >= 0 && value <= 1) t.poison_workspace = value;
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
+  else if (k == "wait_handover_us" && value >= 0) wait_handover_us() = value;  // (process-wide whichever entry point sets it)
   else return false;
   return true;
 }

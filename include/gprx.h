@@ -120,8 +120,8 @@ int gprx_factorize(gprx_handle h, int unit, const double* theta, const double* z
 int gprx_factorize_many(int count, gprx_handle* handles, const int* units, const double* thetas, int mask, double* losses);
 
 /* Batched cells on ONE handle: `count` exact factorisations -- cell i = (units[i], thetas[i]), all on the handle's x,
- * which is what the reference's per-mode loop (gpr.py:272-274, 336-339), its multi-start (gpr.py:149-176) and its
- * differential-evolution population (gpr.py:178-207) evaluate one after the other.  Every kernel of the factorisation
+ * which is what the reference's per-mode loop (gpr.py:272-274, 336-339), its multi-start (_optimize_multi_start, gpr.py:73-109) and its
+ * differential-evolution objective (_optimize_differential_evolutions, gpr.py:44-70) evaluate one after the other.  Every kernel of the factorisation
  * is launched once for all cells (cell index in the grid), so small matrices still fill the GPU.  thetas: (count,
  * n_theta); losses (may be NULL): count training losses, NaN for a cell whose matrix is not positive definite; status
  * (may be NULL): per-cell GPRX_OK / GPRX_ENOTPD.  Returns GPRX_ENOTPD if any cell failed (the others are valid).

@@ -229,3 +229,27 @@ def test_both_predict_paths_agree_with_the_oracle(lib, path):
         assert np.max(np.abs(mean - rm)) <= 1e-8 * np.max(np.abs(rm)) and np.max(np.abs(var - rv) / rv) <= 1e-8
     finally:
         lib.gprx_destroy(h)
+
+
+def test_wait_hands_over_to_stream_synchronize_and_the_next_call_is_clean(lib):
+    """after the event poll of wait_stream has handed over to hipStreamSynchronize, the hipErrorNotReady its polls
+    left behind must not fail the next launch helper (they end in hipGetLastError()).  The hand-over threshold is lowered to 0."""
+    n, d = 2048, 6
+    x, y, xs = make_regression(n, d, n_outputs=1, n_test=5, config=5, unit=77)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, 0, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 1), h)
+    theta = theta_of(1.0, 0.9, 0.3)
+    try:
+        check(lib.gprx_set_tuning(b"wait_handover_us", 0))
+        loss1, loss2 = C.c_double(), C.c_double()
+        grad = np.zeros(3)
+        for _ in range(3):  # every wait of these calls goes through the hand-over; each following launch must come back GPRX_OK
+            check(lib.gprx_factorize(h, 0, ptr(theta), None, 7, C.byref(loss1)), h)
+            check(lib.gprx_objective(h, 0, ptr(theta), None, 7, C.byref(loss2), ptr(grad)), h)
+            mean, var = np.zeros(5), np.zeros(5)
+            check(lib.gprx_predict(h, ptr(xs), 5, ptr(mean), ptr(var), 1), h)
+        assert loss1.value == loss2.value
+    finally:
+        lib.gprx_set_tuning(b"wait_handover_us", 200000)
+        lib.gprx_destroy(h)
