@@ -30,6 +30,7 @@
 #include "potrf_cell.h"
 #include "potrf_dag.h"
 #include "sgpr.h"
+#include "sgpr_fused.h"
 #include "solve.h"
 
 using namespace gprx;
@@ -78,6 +79,8 @@ struct gprx_ctx {
   std::map<int, hipGraphExec_t> graphs;  // unit -> captured single-stream exact factorisation
   std::map<std::pair<int, int>, hipGraphExec_t> sgraphs;  // (cells, with gradient) -> captured sparse batch evaluation
   bool sgraph_off = false;                                // a capture failed once: this handle stays on eager launches
+  int sgpr_fused = 1;                                     // M <= 64: the five-launch evaluation of sgpr_fused.h ("sgpr_fused" tuning key)
+  bool sparse_view = false;                               // the current single-model factorisation lives in cell block 0 of `sarena`
   // current factorisation
   bool factorized = false;
   bool have_linv = false;  // Xinv holds L^-1 of the current factorisation (exact path)
@@ -1026,6 +1029,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
     return fail(h, GPRX_ENOTPD, msg);
   }
   h->factorized = true;
+  h->sparse_view = false;
   h->cur_unit = unit;
   h->variance = t.variance;
   h->noise = s;
@@ -1132,8 +1136,9 @@ int sgpr_gradient(gprx_handle h, int unit, const Theta& t, double* g, double* gz
 // bit-identical values.
 struct SgprLayout {
   int64_t oZ, oY, oP, oAm, oQm, oBm, oInvDL, oInvDB, oSM, oWP, oWHP, oWHQ, oVecs, odZ, oStage, oPart, oWs, oRed, oKs, oPred, ss;
+  int64_t oFU, oFP2;  // fused evaluation (sgpr_fused.h): u partials of the chunks, pass-2 partial blocks
   int64_t part_p, part_q;
-  int width, nsplit;
+  int width, nsplit, p2w;
 };
 
 SgprLayout sgpr_batch_layout(gprx_handle h) {
@@ -1169,6 +1174,9 @@ SgprLayout sgpr_batch_layout(gprx_handle h) {
   L.oRed = take(8);
   L.oKs = take(mp * SGPR_PRED_TILE);                                           // batched predict: Kus tile of this cell
   L.oPred = take(((mp + 255) / 256) * (int64_t)SGPR_PRED_TILE);                // its column-reduction partials
+  L.p2w = (int)round_up(SF_P2_HEAD + NB * d, 2);
+  L.oFU = take((int64_t)L.nsplit * NB);
+  L.oFP2 = take((int64_t)(L.nsplit + 1) * L.p2w);
   L.ss = o;
   return L;
 }
@@ -1177,6 +1185,10 @@ int ensure_sarena(gprx_handle h, int slots, const SgprLayout& L) {
   if (h->sarena_slots >= slots) return GPRX_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   drop_graphs(h);  // captured evaluations hold the addresses of the buffers released below
+  if (h->sparse_view) {  // the single-model factorisation lived in cell block 0 of the arena released below
+    h->sparse_view = false;
+    h->factorized = false;
+  }
   if (h->sarena.p) HIPCHK(h, hipFree(h->sarena.p));
   h->sarena.p = nullptr;
   h->sarena.bytes = 0;
@@ -1212,6 +1224,59 @@ SgprStage sgpr_stage(gprx_handle h, int count, const SgprLayout& L) {
   return s;
 }
 
+// M <= 64: the five launches of sgpr_fused.h (prep, pass 1, mid, pass 2, final) instead of the 21 below; same staging block, same host
+// tail.  "sgpr_fused" = 0 (gprx_set_tuning) keeps the launch sequence -- which larger M always takes.
+int& sgpr_fused_tuning() {
+  static int v = 1;
+  return v;
+}
+static_assert(SF_CHUNK == SPLITK_CHUNK, "the fused evaluation stores its slabs in the split-K workspace of the cell block");
+
+SfParams sgpr_fused_params(gprx_handle h, const SgprLayout& L, bool want_grad) {
+  const int64_t mm = (int64_t)h->mp * h->mp;
+  SfParams p{};
+  p.X = h->X.p;
+  p.Y = h->Y.p;
+  p.arena = h->sarena.p;
+  p.ss = L.ss;
+  p.cpar = h->cellpar.p;
+  p.n = (int)h->n;
+  p.np = (int)h->np;
+  p.m = (int)h->m;
+  p.d = h->d;
+  p.nchunks = L.nsplit;
+  p.oZ = L.oZ;
+  p.oL = L.oQm;
+  p.oLinv = L.oInvDL;
+  p.oLB = L.oBm;
+  p.oLBinv = L.oInvDB;
+  p.oW = L.oSM + SM_W * mm;
+  p.oGQ = L.oSM + SM_GQ * mm;
+  p.oM = L.oVecs;
+  p.oSlab = L.oWs;
+  p.oU = L.oFU;
+  p.oP2 = L.oFP2;
+  p.oRed = L.oRed;
+  p.p2w = L.p2w;
+  p.cellres = h->cellres.p;
+  p.cellres_stride = CELL_RES;
+  p.want_grad = want_grad ? 1 : 0;
+  return p;
+}
+
+int sgpr_fused_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_grad) {
+  hipStream_t st = h->stream;
+  const SgprStage sg = sgpr_stage(h, count, L);
+  const SfParams p = sgpr_fused_params(h, L, want_grad);
+  const int iso = (h->ard || h->dist_form) ? 0 : 1;
+  HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, h->spin + sg.par, h->spin + sg.z, h->cellpar.p));
+  HIPCHK(h, sf_launch_pass1(st, h->kid, h->dist_form, p, count));
+  HIPCHK(h, sf_launch_mid(st, p, count));
+  if (want_grad) HIPCHK(h, sf_launch_pass2(st, h->kid, h->dist_form, iso, p, count));
+  HIPCHK(h, sf_launch_final(st, iso, p, count, h->spin + sg.res, h->spin + sg.red, h->spin + sg.sum, h->spin + sg.dz));
+  return GPRX_OK;
+}
+
 // Device part of one batched evaluation: everything between the staged inputs (parameter table and Z in pinned memory) and
 // the staged outputs (pivot status, reductions, trace sums, dZ in pinned memory).  Nothing here depends on the VALUES of the
 // parameters -- they travel through the cell-parameter table -- so the sequence is captured once per (cells, gradient) into a
@@ -1222,6 +1287,7 @@ int sgpr_batch_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_
   const size_t pitch = sizeof(double) * (size_t)ss;
   hipStream_t st = h->stream;
   double* A0 = h->sarena.p;
+  if (mp == NB && h->sgpr_fused) return sgpr_fused_enqueue(h, count, L, want_grad);
   const SgprStage sg = sgpr_stage(h, count, L);
   // (Tried: the independent branches of the evaluation -- Kuf beside Kuu's factorisation; R, Sinv / T2, T1 / Qinv, m; the
   // two contractions and the noise terms -- on side streams, i.e. parallel branches of the captured graph.  The dependent chain
@@ -1558,6 +1624,7 @@ int gprx_create(int device, int64_t n, int d, int64_t m, int kernel_id, int ard,
   h->mp = round_up(m, NB);
   h->tune = potrf_tuning();  // a private copy: later gprx_set_tuning calls (process defaults) do not reach this handle
   h->predict_path = predict_path_tuning();
+  h->sgpr_fused = sgpr_fused_tuning();
   // normal priority on purpose: measured on MI355X, raised/lowered stream priorities do nothing for a single
   // cell and cut the throughput of several concurrent cells by up to 2x
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1696,6 +1763,33 @@ static int objective_impl(gprx_handle h, int unit, const double* theta, const do
   const Theta t = decode_theta(h, theta);
   const bool sparse = h->m != 0;
   double value = 0.0;  // LML (exact) or ELBO (sparse)
+  if (sparse && h->mp == NB && h->sgpr_fused && h->d <= CELL_PAR - CELL_PAR_LS && !h->profiling) {
+    // M <= 64: one model is a batch of one cell through the five launches of sgpr_fused.h -- the same kernels, the same summation
+    // order as any batch (a model evaluated alone and inside a batch agree bit for bit); the factorisation stays in cell block 0,
+    // where gprx_predict reads it (sparse_view)
+    if (!z) return fail(h, GPRX_EINVAL, "z (inducing inputs) is null for a sparse model");
+    const int64_t nz = h->m * h->d;
+    for (int64_t e = 0; e < nz; ++e)
+      if (!std::isfinite(z[e])) return fail(h, GPRX_EINVAL, "z is not finite");
+    std::vector<double> g(grad ? h->ntheta : 0), gzv(grad ? nz : 0);
+    int st = GPRX_OK;
+    if ((rc = sgpr_objective_batch(h, 1, &unit, &t, z, &value, grad ? g.data() : nullptr, grad ? gzv.data() : nullptr, &st))) return rc;
+    if (loss) *loss = -(value + log_prior(h, t, mask));
+    if (grad) {
+      chain_rule(h, t, mask, g.data(), grad);
+      double* gz = grad + h->ntheta;
+      for (int64_t e = 0; e < nz; ++e) gz[e] = (mask & GPRX_TRAIN_Z) ? -gzv[e] : 0.0;
+    }
+    for (auto& ev : h->ev) HIPCHK(h, hipEventRecord(ev, h->stream));
+    for (double& tm : h->timings) tm = 0.0;
+    h->factorized = true;
+    h->sparse_view = true;
+    h->cur_unit = unit;
+    h->variance = t.variance;
+    h->noise = t.noise;
+    h->ls = t.ls;
+    return GPRX_OK;
+  }
   // exact model with gradient: ONE stream synchronisation for both halves, and alpha from the inverse the gradient builds (the
   // 64 dependent launches of the backward substitution drop out of the evaluation); a non-PD matrix is reported by the
   // factorisation's status as before (the gradient launches behind it are then wasted, not wrong: nothing is read back)
@@ -2073,6 +2167,7 @@ int gprx_predict_dev(gprx_handle h, const double* xs_dev, int64_t ns, double* me
   if (ns < 0 || (ns > 0 && (!xs_dev || !mean_dev || !var_dev))) return fail(h, GPRX_EINVAL, "null argument");
   hipStream_t st = h->stream;
   const int rows_per_chunk = 256;
+  if (h->m != 0 && h->sparse_view) return sgpr_predict_batch(h, 1, xs_dev, ns, mean_dev, var_dev, include_noise);  // cell block 0
   if (h->m != 0) {
     // gpflow SGPR.predict_f: tmp1 = L^-1 Kus, tmp2 = LB^-1 tmp1, mean = tmp2^T c,
     // var = v + colsum(tmp2^2) - colsum(tmp1^2) (+ s for predict_y)
@@ -3080,7 +3175,7 @@ int gprx_panel_stamps(unsigned long long* out64) {
 #endif
 
 namespace {
-bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int value) {
+bool apply_tuning(PotrfTuning& t, int& predict_path, int& fused, const std::string& k, int value) {
   if (k == "panel_width" && (value == 0 || value == 64 || value == 128)) t.panel_width = value;
   else if (k == "outer_block" && value >= 0 && value % 128 == 0) t.outer_block = value;
   else if (k == "update_tile" && (value == 0 || value == 64 || value == 128)) t.update_tile = value;
@@ -3098,6 +3193,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
   else if (k == "split_updates" && value >= 0 && value <= 1) t.split_updates = value;
   else if (k == "poison_workspace" && value >= 0 && value <= 1) t.poison_workspace = value;
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
+  else if (k == "sgpr_fused" && value >= 0 && value <= 1) fused = value;
   else if (k == "wait_handover_us" && value >= 0) wait_handover_us() = value;  // (process-wide whichever entry point sets it)
   else return false;
   return true;
@@ -3106,13 +3202,13 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, const std::string& k, int v
 
 int gprx_set_tuning(const char* key, int value) {
   if (!key) return fail(nullptr, GPRX_EINVAL, "null key");
-  if (!apply_tuning(potrf_tuning(), predict_path_tuning(), key, value)) return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
+  if (!apply_tuning(potrf_tuning(), predict_path_tuning(), sgpr_fused_tuning(), key, value)) return fail(nullptr, GPRX_EINVAL, "unknown tuning key or bad value");
   return GPRX_OK;
 }
 
 int gprx_set_handle_tuning(gprx_handle h, const char* key, int value) {
   if (!h || !key) return fail(h, GPRX_EINVAL, "null argument");
-  if (!apply_tuning(h->tune, h->predict_path, key, value)) return fail(h, GPRX_EINVAL, "unknown tuning key or bad value");
+  if (!apply_tuning(h->tune, h->predict_path, h->sgpr_fused, key, value)) return fail(h, GPRX_EINVAL, "unknown tuning key or bad value");
   if (hipSetDevice(h->device) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) drop_graphs(h);  // captured with the old schedule
   return GPRX_OK;
 }

@@ -42,7 +42,7 @@ __device__ __forceinline__ double rsqrt_f64(double a) {
 // degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18), result scaled by 2^n with v_ldexp_f64.
 // The coefficients live in constant memory: they are fetched with scalar loads and enter v_fma_f64 as SGPR
 // operands, so the Horner chain needs no per-step constant moves into vector registers.
-__constant__ double kExpCoef[16] = {1.6059043836821613e-10, 2.08767569878681e-09,  2.505210838544172e-08, 2.755731922398589e-07,
+static __constant__ double kExpCoef[16] = {1.6059043836821613e-10, 2.08767569878681e-09,  2.505210838544172e-08, 2.755731922398589e-07,
                                     2.7557319223985893e-06, 2.48015873015873e-05,  1.984126984126984e-04, 1.388888888888889e-03,
                                     8.333333333333333e-03,  4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
                                     1.0,                    1.0,                   -6.93147180369123816490e-01, -1.90821492927058770002e-10};
@@ -64,7 +64,7 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 // the 64-entry table sits in LDS (512 bytes = every bank pair exactly once: a wave's 64 different indices read without conflicts).
 // Used by the kernel-matrix build only; the gradient passes keep exp_nonpos.  Measured against numpy's exp on 1e7 arguments in
 // tests/test_gpu_blocks.py (<= 1 ulp).
-__constant__ double kExp2Tab[64] = {
+static __constant__ double kExp2Tab[64] = {
     0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
     0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
     0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,

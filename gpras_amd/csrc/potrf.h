@@ -18,6 +18,7 @@
 #include <utility>
 #include <vector>
 
+#include "chain64.h"
 #include "gemm_f64.h"
 #include "gprx_common.h"
 
@@ -62,7 +63,7 @@ struct PanelGeom {
   static constexpr int kWgRows = 64 * RT;      // rows held by one workgroup (rows 0..63 = the diagonal block)
   static constexpr int kOwnRows = 64 * RT - NB;  // rows of A21 per workgroup
 };
-constexpr int PSUB = 9;          // LDS row stride of the 8-column sub-panel buffers (row-per-lane b64 access conflict-free)
+// (PSUB, the LDS row stride of the 8-column sub-panel buffers, lives in chain64.h)
 
 // State shared by the unrolled sub-panel steps.
 struct PanelCtx {

@@ -5,6 +5,7 @@
 // cell kernel) does not include the scheduler (task queue, version counters, persistent kernel), which is an opt-in of its own.
 #pragma once
 #include "gemm_f64.h"
+#include "chain64.h"
 #include "gprx_common.h"
 #include "potrf.h"
 
@@ -76,119 +77,6 @@ __device__ __forceinline__ void store_inverse_block(__amdgpu_buffer_rsrc_t ri, c
   for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(iv[e].x), "v"(iv[e].y));
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding global store and load of the wave
-// (s_waitcnt vmcnt(0)), i.e. it would drain the write-through stores at every barrier
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// ---- chain workgroup ---------------------------------------------------------------------------------------------------
-// Rows of the chain's panel: workgroup rows 0..63 = the diagonal block, 64..127 = identity rows (they come out as L^-T).
-// Wave w holds band w of each: acc[0] = diagonal rows 16 w .. 16 w + 15, acc[1] = identity rows 16 w .. 16 w + 15 -- so the
-// band a wave needs for the next step (its rows of the updated diagonal block) is the band it computes.
-struct ChainCtx {
-  double* sIn;
-  double* sX;
-  int tid, wave, g, r;
-  int bad;
-};
-
-#ifdef GPRX_CHAIN_STAMPS
-__device__ unsigned long long g_chain_stamps[16];
-#define CSTAMP(i) if constexpr (P == 3) { if (c.tid == 0) g_chain_stamps[i] = __builtin_amdgcn_s_memtime(); }
-#else
-#define CSTAMP(i)
-#endif
-
-template <int P>
-__device__ __forceinline__ void chain_step(d4 (&acc)[2][4], ChainCtx& c) {
-  constexpr int C0 = 8 * P;
-  CSTAMP(0)
-  constexpr int KT = C0 / 16;
-  constexpr int HALF = P & 1;
-  // accumulators -> LDS (the lanes that hold these 8 columns)
-  if ((c.r >> 3) == HALF) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) c.sIn[(64 * rt + 16 * c.wave + c.g + 4 * q) * PSUB + (c.r & 7)] = acc[rt][KT][q];
-  }
-  CSTAMP(1)
-  lds_barrier();
-  CSTAMP(2)
-  // every thread factors the 8 x 8 diagonal sub-block (rows C0 .. C0 + 7 of the diagonal block): potrf.h panel_step
-  double l[8][8], rinv[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int k = 0; k <= j; ++k) l[j][k] = c.sIn[(C0 + j) * PSUB + k];
-  CSTAMP(3)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    double s = l[j][j];
-#pragma unroll
-    for (int m = 0; m < j; ++m) s = __builtin_fma(-l[j][m], l[j][m], s);
-    if (!(s > 0.0)) {
-      if (c.bad == 0) c.bad = C0 + j + 1;
-      s = 1.0;
-    }
-    const double ri = rsqrt_f64(s);
-    rinv[j] = ri;
-    l[j][j] = s * ri;
-#pragma unroll
-    for (int i = j + 1; i < 8; ++i) {
-      double t = l[i][j];
-#pragma unroll
-      for (int m = 0; m < j; ++m) t = __builtin_fma(-l[i][m], l[j][m], t);
-      l[i][j] = t * ri;
-    }
-  }
-  CSTAMP(4)
-  if (c.tid < 128) {
-    const int zero_above = c.tid < NB ? c.tid : (1 << 30);
-    double x[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double t = c.sIn[c.tid * PSUB + k];
-#pragma unroll
-      for (int m = 0; m < k; ++m) t = __builtin_fma(-x[m], l[k][m], t);
-      x[k] = (C0 + k > zero_above) ? 0.0 : t * rinv[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) c.sX[c.tid * PSUB + k] = x[k];
-  }
-  CSTAMP(5)
-  lds_barrier();
-  CSTAMP(6)
-  if constexpr (C0 + 8 < NB) {
-    constexpr int KT0 = (C0 + 8) / 16;
-    double fa[2][2], fb[4][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fa[rt][ks] = -c.sX[(64 * rt + 16 * c.wave + c.r) * PSUB + 4 * ks + c.g];
-#pragma unroll
-    for (int kt = KT0; kt < 4; ++kt) {
-      const int kk = kt * 16 + c.r;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) fb[kt][ks] = (kk >= C0 + 8) ? c.sX[kk * PSUB + 4 * ks + c.g] : 0.0;
-    }
-#pragma unroll
-    for (int kt = KT0; kt < 4; ++kt)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][0], fb[kt][0], acc[rt][kt], 0, 0, 0);
-        acc[rt][kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[rt][1], fb[kt][1], acc[rt][kt], 0, 0, 0);
-      }
-  }
-  CSTAMP(7)
-  if ((c.r >> 3) == HALF) {  // solved values back into the accumulators
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[rt][KT][q] = c.sX[(64 * rt + 16 * c.wave + c.g + 4 * q) * PSUB + (c.r & 7)];
-  }
-  CSTAMP(8)
-}
-
 // ---- workers -------------------------------------------------------------------------------------------------------------
 // acc (this wave's 32 x 32 quarter of a 64 x 64 tile) += A B^T over one 64-deep block; ia / ib: the operands' four stage
 // images [64 rows][16 k] in LDS, chunks XOR-swizzled (gemm_f64.h kc_swz)

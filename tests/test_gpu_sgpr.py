@@ -302,3 +302,47 @@ def test_batched_sparse_evaluations_from_two_threads_on_two_handles(lib):
         assert len(results[k]) == 6
         for losses, grads, ok in results[k]:
             assert ok.all() and np.array_equal(losses, want[0]) and np.array_equal(grads, want[1])
+
+
+@pytest.mark.parametrize("kernel,n,d,m,ard,form", [("RBF", 1100, 10, 50, False, 0), ("Matern52", 700, 20, 64, True, 0), ("Matern12", 500, 3, 33, False, 1),
+                                                  ("Exponential", 300, 40, 17, True, 1), ("Matern32", 257, 1, 1, False, 0)])
+def test_fused_evaluation_agrees_with_the_launch_sequence_and_does_not_depend_on_the_batch(lib, kernel, n, d, m, ard, form):
+    """M <= 64 takes the five-launch evaluation of sgpr_fused.h (tuning key "sgpr_fused", default 1).  Its values agree with the
+    round-4 launch sequence ("sgpr_fused" = 0) to rounding -- and differ from it in the last bits, which shows that the fused
+    kernels ran --, with the oracle to 1e-9 / 1e-7, and a cell evaluated alone equals the same cell inside a batch bit for bit
+    (fixed chunks of 256 columns, chunk order: sgpr_fused.h "Determinism").  d > 16 takes the restaging variants, d = 40 with ARD the
+    four-chunk accumulators; form 1 is gpflow's expanded distance."""
+    cells = 7
+    x, y, _ = make_regression(n, d, n_outputs=3, n_test=0, config=14, unit=n + m + d)
+    h = make_handle(lib, n, d, m, kernel, ard, x, y)
+    nt = 2 + (d if ard else 1)
+    try:
+        check(lib.gprx_set_distance_form(h, form), h)
+        rng = np.random.default_rng(n)
+        units = np.ascontiguousarray(rng.integers(0, 3, size=cells), dtype=np.int32)
+        thetas = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, nt)))
+        zs = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] + 1e-3 * rng.standard_normal((m, d)) for _ in range(cells)]))
+        out = {}
+        for fused in (1, 0):
+            check(lib.gprx_set_handle_tuning(h, b"sgpr_fused", fused), h)
+            losses, grads = np.zeros(cells), np.zeros((cells, nt + m * d))
+            check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), ptr(zs), 15, ptr(losses), ptr(grads)), h)
+            out[fused] = (losses, grads)
+        assert np.max(np.abs(out[1][0] - out[0][0]) / np.abs(out[0][0])) <= 1e-11
+        scale = np.max(np.abs(out[0][1]), axis=1, keepdims=True)
+        assert np.max(np.abs(out[1][1] - out[0][1]) / scale) <= 1e-8
+        assert not np.array_equal(out[1][1], out[0][1])  # (another summation order: the last bits differ somewhere)
+        check(lib.gprx_set_handle_tuning(h, b"sgpr_fused", 1), h)
+        for c in (0, cells - 1):
+            th, zc = np.ascontiguousarray(thetas[c]), np.ascontiguousarray(zs[c])
+            l1, g1 = np.zeros(1), np.zeros((1, nt + m * d))
+            u1 = np.ascontiguousarray(units[c:c + 1])
+            check(lib.gprx_objective_batch(h, 1, ptr(u1), ptr(th), ptr(zc), 15, ptr(l1), ptr(g1)), h)
+            assert l1[0] == out[1][0][c] and np.array_equal(g1[0], out[1][1][c])
+            wl = th[1:-1] if ard else float(th[1])
+            ref_loss, g = osg.loss_and_grad(kernel, x, y[:, units[c]], zc, float(th[0]), wl, float(th[-1]), form="expanded" if form else "direct")
+            ref = np.concatenate([[g["variance"]], np.atleast_1d(g["lengthscales"]), [g["noise"]], np.asarray(g["Z"]).ravel()])
+            assert abs(l1[0] - ref_loss) <= 1e-9 * abs(ref_loss)
+            assert np.max(np.abs(g1[0] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref)))
+    finally:
+        lib.gprx_destroy(h)
