@@ -30,6 +30,7 @@
 #include "potrf_cell.h"
 #include "potrf_dag.h"
 #include "sgpr.h"
+#include "sgpr_asm.h"
 #include "sgpr_fused.h"
 #include "solve.h"
 
@@ -80,6 +81,10 @@ struct gprx_ctx {
   std::map<std::pair<int, int>, hipGraphExec_t> sgraphs;  // (cells, with gradient) -> captured sparse batch evaluation
   bool sgraph_off = false;                                // a capture failed once: this handle stays on eager launches
   int sgpr_fused = 1;                                     // M <= 64: the five-launch evaluation of sgpr_fused.h ("sgpr_fused" tuning key)
+  Buf adam_dev;                                           // device state of the resident Adam loop (sgpr_adam_resident)
+  double* adam_pin = nullptr;                             // pinned: stop flags of the cells + the error word, read every few steps
+  size_t adam_pin_bytes = 0;
+  unsigned long long* sf_stamps = nullptr;                // development aid (gprx_sf_stamps): phase stamps of the fused sparse kernels
   bool sparse_view = false;                               // the current single-model factorisation lives in cell block 0 of `sarena`
   // current factorisation
   bool factorized = false;
@@ -219,13 +224,12 @@ int ensure_zeroed(gprx_handle h, Buf& b, size_t bytes) {
 }
 
 // ---- scalar transforms (gpflow positive() / LogNormal(0,1) priors; see oracle/transforms.py) ------
-double softplus(double w) { return w > 0 ? w + std::log1p(std::exp(-w)) : std::log1p(std::exp(w)); }
-double sigmoid(double w) { return 0.5 * (1.0 + std::tanh(0.5 * w)); }
-double ln_logpdf(double u) {
-  const double lu = std::log(u);
-  return -lu - 0.5 * std::log(2.0 * M_PI) - 0.5 * lu * lu;
-}
-double ln_dlogpdf(double u) { return -(1.0 + std::log(u)) / u; }
+// (round 5: the portable forms of px_math.h -- the device-resident Adam loop evaluates the same functions inside a kernel and must get the
+// same bits as this host code)
+double softplus(double w) { return px_softplus(w); }
+double sigmoid(double w) { return px_sigmoid(w); }
+double ln_logpdf(double u) { return px_ln_logpdf(u); }
+double ln_dlogpdf(double u) { return px_ln_dlogpdf(u); }
 
 __global__ void set_rhs_rows_kernel(double* dst, int64_t ld, const double* y, int n, int np, int rows) {
   const int64_t total = (int64_t)rows * np;
@@ -551,7 +555,7 @@ int exact_factorize_finish(gprx_handle h, double* lml_out) {
   }
   h->factorized = true;
   h->have_linv = false;
-  if (lml_out) *lml_out = -0.5 * red[1] - red[0] - 0.5 * (double)h->n * std::log(2.0 * M_PI);
+  if (lml_out) *lml_out = -0.5 * red[1] - red[0] - 0.5 * (double)h->n * PX_LOG_2PI;
   return GPRX_OK;
 }
 
@@ -770,7 +774,7 @@ int exact_factorize_batch(gprx_handle h, int count, const int* units, const Thet
       continue;
     }
     const double* r = res + (size_t)c * CELL_RES;
-    if (lml_out) lml_out[c] = -0.5 * r[1] - r[0] - 0.5 * (double)h->n * std::log(2.0 * M_PI);
+    if (lml_out) lml_out[c] = -0.5 * r[1] - r[0] - 0.5 * (double)h->n * PX_LOG_2PI;
   }
   // a single-cell view into a slot of this batch is stale now
   for (Buf* b : {&h->Kmat, &h->invD, &h->alpha})
@@ -1037,8 +1041,7 @@ int sgpr_factorize(gprx_handle h, int unit, const Theta& t, const double* z, dou
   h->elbo_trAAT = red[2];
   const double nn = (double)h->n;
   if (elbo_out)
-    *elbo_out = -0.5 * nn * std::log(2.0 * M_PI) - red[0] - 0.5 * nn * std::log(s) - 0.5 * (nn * t.variance / s - red[2]) -
-                0.5 * (h->yy[unit] / s - red[1]);
+    *elbo_out = sgpr_asm_elbo(nn, h->yy[unit], t.variance, s, red);
   return GPRX_OK;
 }
 
@@ -1261,13 +1264,22 @@ SfParams sgpr_fused_params(gprx_handle h, const SgprLayout& L, bool want_grad) {
   p.cellres = h->cellres.p;
   p.cellres_stride = CELL_RES;
   p.want_grad = want_grad ? 1 : 0;
+  p.stamps = h->sf_stamps;
   return p;
 }
 
 int sgpr_fused_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_grad) {
   hipStream_t st = h->stream;
   const SgprStage sg = sgpr_stage(h, count, L);
-  const SfParams p = sgpr_fused_params(h, L, want_grad);
+  SfParams p = sgpr_fused_params(h, L, want_grad);
+  // (the Kuu workgroups of launch 4 are separate while the whole launch is resident at once: one 512-thread workgroup per CU)
+  static const int n_cus = [] {
+    int v = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v;
+  }();
+  p.q_appended = (int64_t)count * (p.nchunks + 1) > n_cus ? 1 : 0;
   const int iso = (h->ard || h->dist_form) ? 0 : 1;
   HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, h->spin + sg.par, h->spin + sg.z, h->cellpar.p));
   HIPCHK(h, sf_launch_pass1(st, h->kid, h->dist_form, p, count));
@@ -1518,22 +1530,11 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
     }
     const double* red = hred + (size_t)c * 8;
     const double s = ts[c].noise, v = ts[c].variance;
-    elbo_out[c] = -0.5 * nn * std::log(2.0 * M_PI) - red[0] - 0.5 * nn * std::log(s) - 0.5 * (nn * v / s - red[2]) -
-                  0.5 * (h->yy[units[c]] / s - red[1]);
+    elbo_out[c] = sgpr_asm_elbo(nn, h->yy[units[c]], v, s, red);  // (sgpr_asm.h: the resident Adam loop forms the same sums on the device)
     if (!g) continue;
     const double* hs = hsum + (size_t)c * 2 * width;
     double* gc = g + (size_t)c * h->ntheta;
-    const double tr_sinv_pp = s * ((double)mp - red[3]);
-    const double tr_qinv_pp = s * red[2];
-    gc[0] = -nn / (2.0 * s) + hs[0] + hs[width];
-    if (h->ard) {
-      for (int k = 0; k < d; ++k) gc[1 + k] = hs[2 + k] + hs[width + 2 + k];
-    } else {
-      double acc = 0.0;
-      for (int k = 0; k < d; ++k) acc += hs[2 + k] + hs[width + 2 + k];
-      gc[1] = acc;
-    }
-    gc[1 + h->nlen] = (tr_sinv_pp - tr_qinv_pp + red[4] + nn * v) / (2.0 * s * s) - nn / (2.0 * s);
+    for (int k = 0; k < h->ntheta; ++k) gc[k] = sgpr_asm_dparam(k, h->nlen, h->ard, d, width, nn, mp, v, s, red, hs);
     if (gz) std::memcpy(gz + (size_t)c * m * d, hdz + (size_t)c * m * d, sizeof(double) * m * d);
   }
   return first_error;
@@ -1579,6 +1580,128 @@ int sgpr_predict_batch(gprx_handle h, int count, const double* xs_dev, int64_t n
     hipLaunchKernelGGL(colreduce_final, fgrid, dim3(256), 0, st, (const double*)(A0 + L.oPred), nchunks, ts, 0.0, 1.0, 1, vars_dev + t0, ss, ns);
   }
   HIPCHK(h, hipGetLastError());
+  return GPRX_OK;
+}
+
+// gprx_adam_batch for sparse models with M <= 64: the loop RESIDENT on the device.  A step is five launches (sgpr_fused.h: prep with the
+// positive transforms evaluated on the device, pass 1, mid, pass 2, sf_adam_kernel = partial sums + loss + gradient + Keras's update + the
+// stop rule of gpr.py:160-171); cells that have stopped return at once from every launch.  The host enqueues `check_every` steps, then reads
+// the stop flags (count + 1 ints through pinned memory) -- no gradient, loss or parameter crosses the host link during the run (round 4:
+// every step synchronised, downloaded the gradients, updated on the host and uploaded).  Same variables as the host-stepped loop, bit
+// for bit (sgpr_asm.h, px_math.h; tests/test_gpu_gpras.py).  A cell whose Kuu or B stops being positive definite ends the call with
+// GPRX_ENOTPD at the next check; the other cells may then be up to check_every - 1 steps past that evaluation.
+int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta, double* z, int mask, int max_iter, int* n_evals, int* batches) {
+  const SgprLayout L = sgpr_batch_layout(h);
+  int rc;
+  if ((rc = ensure_sarena(h, count, L))) return rc;
+  hipStream_t st = h->stream;
+  const int nt = h->ntheta;
+  const int64_t nz = h->m * h->d, gw = nt + nz;
+  // ---- device state: doubles first, then ints ----
+  const size_t n_dbl = (size_t)count * nt + 2 * (size_t)count * gw + 2 * (size_t)count + (size_t)max_iter + 1 + (size_t)h->n_units;
+  const size_t n_int = 5 * (size_t)count + 1;
+  if ((rc = ensure(h, h->adam_dev, sizeof(double) * n_dbl + sizeof(int) * n_int))) return rc;
+  const size_t pin_need = sizeof(int) * ((size_t)count + 1);
+  if (h->adam_pin_bytes < pin_need) {
+    if (h->adam_pin) HIPCHK(h, hipHostFree(h->adam_pin));
+    h->adam_pin = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&h->adam_pin, pin_need, hipHostMallocDefault));
+    h->adam_pin_bytes = pin_need;
+  }
+  SfAdam ad{};
+  double* dp = h->adam_dev.p;
+  ad.theta = dp;                 dp += (size_t)count * nt;
+  ad.mom = dp;                   dp += (size_t)count * gw;
+  ad.vel = dp;                   dp += (size_t)count * gw;
+  ad.best = dp;                  dp += count;
+  ad.loss = dp;                  dp += count;
+  double* d_alpha = dp;          dp += (size_t)max_iter + 1;
+  double* d_yy = dp;             dp += h->n_units;
+  int* ip = reinterpret_cast<int*>(dp);
+  ad.stale = ip;                 ip += count;
+  ad.active = ip;                ip += count;
+  ad.n_evals = ip;               ip += count;
+  ad.tstep = ip;                 ip += count;
+  int* d_units = ip;             ip += count;
+  ad.error = ip;
+  ad.units = d_units;
+  ad.alpha = d_alpha;
+  ad.yy = d_yy;
+  ad.nt = nt;
+  ad.nlen = h->nlen;
+  ad.ard = h->ard;
+  ad.mask = mask;
+  ad.max_iter = max_iter;
+  // ---- initial state (host vectors live until the synchronisation below) ----
+  std::vector<double> hd(n_dbl, 0.0);
+  std::vector<int> hi(n_int, 0);
+  std::memcpy(hd.data(), theta, sizeof(double) * (size_t)count * nt);
+  {
+    double* hbest = hd.data() + (ad.best - h->adam_dev.p);
+    for (int c = 0; c < count; ++c) hbest[c] = std::numeric_limits<double>::infinity();
+    double* halpha = hd.data() + (d_alpha - h->adam_dev.p);
+    for (int t = 1; t <= max_iter; ++t)
+      halpha[t] = ADAM_LR * std::sqrt(1.0 - std::pow(ADAM_BETA2, (double)t)) / (1.0 - std::pow(ADAM_BETA1, (double)t));  // gprx_adam_batch's expression
+    std::memcpy(hd.data() + (d_yy - h->adam_dev.p), h->yy.data(), sizeof(double) * h->n_units);
+    for (int c = 0; c < count; ++c) {
+      hi[(size_t)count + c] = 1;          // active
+      hi[4 * (size_t)count + c] = units[c];
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(h->adam_dev.p, hd.data(), sizeof(double) * n_dbl, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(ad.stale, hi.data(), sizeof(int) * n_int, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpy2DAsync(h->sarena.p + L.oZ, sizeof(double) * (size_t)L.ss, z, sizeof(double) * (size_t)nz, sizeof(double) * (size_t)nz, count,
+                             hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  SfParams p = sgpr_fused_params(h, L, true);
+  p.active = ad.active;
+  int n_cus = 256;
+  hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, h->device);
+  p.q_appended = (int64_t)count * (p.nchunks + 1) > n_cus ? 1 : 0;
+  const int iso = (h->ard || h->dist_form) ? 0 : 1;
+  static const int check_every = [] {
+    const char* e = getenv("GPRX_ADAM_CHECK_EVERY");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 25;
+  }();
+  int* flags = reinterpret_cast<int*>(h->adam_pin);
+  int error_cell = 0;
+  h->factorized = false;  // the cell blocks are overwritten
+  h->sparse_view = false;
+  for (int done = 0; done < max_iter;) {
+    const int k = std::min(check_every, max_iter - done);
+    for (int i = 0; i < k; ++i) {
+      HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, nullptr, nullptr, h->cellpar.p, &ad));
+      HIPCHK(h, sf_launch_pass1(st, h->kid, h->dist_form, p, count));
+      HIPCHK(h, sf_launch_mid(st, p, count));
+      HIPCHK(h, sf_launch_pass2(st, h->kid, h->dist_form, iso, p, count));
+      HIPCHK(h, sf_launch_adam(st, iso, p, count, ad));
+    }
+    done += k;
+    HIPCHK(h, hipMemcpyAsync(flags, ad.active, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(flags + count, ad.error, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, wait_stream(h, st));
+    error_cell = flags[count];
+    bool any = false;
+    for (int c = 0; c < count; ++c) any = any || flags[c] != 0;
+    if (error_cell != 0 || !any) break;
+  }
+  // ---- results ----
+  HIPCHK(h, hipMemcpyAsync(theta, ad.theta, sizeof(double) * (size_t)count * nt, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpy2DAsync(z, sizeof(double) * (size_t)nz, h->sarena.p + L.oZ, sizeof(double) * (size_t)L.ss, sizeof(double) * (size_t)nz, count,
+                             hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(n_evals, ad.n_evals, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  if (batches) {
+    int mx = 0;
+    for (int c = 0; c < count; ++c) mx = std::max(mx, n_evals[c]);
+    *batches = mx;
+  }
+  if (error_cell != 0) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "cell %d: Kuu or B not positive definite", error_cell - 1);
+    return fail(h, GPRX_ENOTPD, msg);
+  }
   return GPRX_OK;
 }
 
@@ -1663,6 +1786,9 @@ int gprx_destroy(gprx_handle h) {
     if (b->p && !b->borrowed) hipFree(b->p);
   if (h->bpin) hipHostFree(h->bpin);
   if (h->spin) hipHostFree(h->spin);
+  if (h->sf_stamps) hipFree(h->sf_stamps);
+  if (h->adam_dev.p) hipFree(h->adam_dev.p);
+  if (h->adam_pin) hipHostFree(h->adam_pin);
   for (auto& ev : h->bev)
     if (ev) hipEventDestroy(ev);
   if (h->stagger_evt) hipEventDestroy(h->stagger_evt);
@@ -1747,10 +1873,10 @@ int gprx_set_data(gprx_handle h, const double* x, const double* y, int n_units) 
 
 // priors and softplus chain rule on the hyperparameter part of a gradient; loss = -(value + log prior)
 void chain_rule(gprx_handle h, const Theta& t, int mask, const double* g, double* grad) {
-  grad[0] = (mask & GPRX_TRAIN_VARIANCE) ? -(g[0] + ln_dlogpdf(t.variance)) * sigmoid(t.w_var) : 0.0;
+  grad[0] = sgpr_asm_chain(g[0], t.variance, t.w_var, (mask & GPRX_TRAIN_VARIANCE) != 0);
   for (int k = 0; k < h->nlen; ++k)
-    grad[1 + k] = (mask & GPRX_TRAIN_LENGTHSCALE) ? -(g[1 + k] + ln_dlogpdf(t.ls[k])) * sigmoid(t.w_len[k]) : 0.0;
-  grad[1 + h->nlen] = (mask & GPRX_TRAIN_NOISE) ? -(g[1 + h->nlen] + ln_dlogpdf(t.noise)) * sigmoid(t.w_noise) : 0.0;
+    grad[1 + k] = sgpr_asm_chain(g[1 + k], t.ls[k], t.w_len[k], (mask & GPRX_TRAIN_LENGTHSCALE) != 0);
+  grad[1 + h->nlen] = sgpr_asm_chain(g[1 + h->nlen], t.noise, t.w_noise, (mask & GPRX_TRAIN_NOISE) != 0);
 }
 
 static int objective_impl(gprx_handle h, int unit, const double* theta, const double* z, int mask, double* loss, double* grad) {
@@ -1898,8 +2024,18 @@ int gprx_adam_batch(gprx_handle h, int count, const int* units, double* theta, d
   bool any = false;
   for (char t : train) any = any || t;
   if (!any) return GPRX_OK;  // nothing trainable: no step can change anything (optimizers._optimize_adam returns at once)
-  const double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, eps = 1e-7, tol = 10e-6;
-  const int patience = 50;
+  static const bool adam_on_host = getenv("GPRX_ADAM_HOST") && atoi(getenv("GPRX_ADAM_HOST")) != 0;  // escape hatch: the host-stepped loop
+  if (h->m != 0 && h->mp == NB && h->sgpr_fused && h->d <= CELL_PAR - CELL_PAR_LS && !adam_on_host && max_iter > 0) {
+    for (int i = 0; i < count; ++i) {
+      if (units[i] < 0 || units[i] >= h->n_units) return fail(h, GPRX_EINVAL, "unit out of range (call gprx_set_data first)");
+      for (int k = 0; k < nt; ++k)
+        if (!std::isfinite(theta[(size_t)i * nt + k])) return fail(h, GPRX_EINVAL, "theta is not finite");
+    }
+    for (int64_t e = 0; e < (int64_t)count * nz; ++e)
+      if (!std::isfinite(z[e])) return fail(h, GPRX_EINVAL, "z is not finite");
+    return sgpr_adam_resident(h, count, units, theta, z, mask, max_iter, n_evals, batches);
+  }
+  const double lr = ADAM_LR, beta1 = ADAM_BETA1, beta2 = ADAM_BETA2;
   std::vector<double> mom((size_t)count * gw, 0.0), vel((size_t)count * gw, 0.0), best(count, std::numeric_limits<double>::infinity());
   std::vector<int> stale(count, 0), active(count);
   for (int i = 0; i < count; ++i) active[i] = i;
@@ -1927,20 +2063,10 @@ int gprx_adam_batch(gprx_handle h, int count, const int* units, double* theta, d
       const double* g = &grads[(size_t)j * gw];
       for (int64_t e = 0; e < gw; ++e) {
         if (!train[e]) continue;
-        const double ge = g[e];
-        mo[e] = beta1 * mo[e] + (1.0 - beta1) * ge;
-        ve[e] = beta2 * ve[e] + ((1.0 - beta2) * ge) * ge;
         double* x = e < nt ? theta + (size_t)i * nt + e : z + (size_t)i * nz + (e - nt);
-        *x = *x - (alpha * mo[e]) / (std::sqrt(ve[e]) + eps);
+        adam_element(g[e], alpha, mo[e], ve[e], *x);  // (sgpr_asm.h: the resident loop's kernel runs the same function)
       }
-      const double loss = losses[j];
-      if (((best[i] - loss) / std::fabs(loss)) > tol) {
-        best[i] = loss;
-        stale[i] = 0;
-        next.push_back(i);
-      } else if (++stale[i] <= patience) {
-        next.push_back(i);
-      }
+      if (adam_keep_running(losses[j], best[i], stale[i])) next.push_back(i);
     }
     active.swap(next);
   }
@@ -3167,6 +3293,24 @@ int gprx_cell_acc(unsigned long long* out16, int reset) {
   return 0;
 }
 #endif
+// Development aid: phase stamps (s_memtime, shader clocks) of workgroup (0, 0) of each of the five fused sparse kernels (sgpr_fused.h
+// SF_STAMP) for the evaluations that follow enable = 1; out (may be null): SF_STAMP_WORDS words of the last evaluation.
+int gprx_sf_stamps(gprx_handle h, int enable, unsigned long long* out) {
+  if (!h) return fail(h, GPRX_EINVAL, "null handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (out && h->sf_stamps) HIPCHK(h, copy_sync(out, h->sf_stamps, sizeof(unsigned long long) * SF_STAMP_WORDS, hipMemcpyDeviceToHost));
+  if (enable && !h->sf_stamps) {
+    HIPCHK(h, hipMalloc((void**)&h->sf_stamps, sizeof(unsigned long long) * SF_STAMP_WORDS));
+    HIPCHK(h, memset_sync(h->sf_stamps, 0, sizeof(unsigned long long) * SF_STAMP_WORDS));
+    drop_graphs(h);
+  } else if (!enable && h->sf_stamps) {
+    HIPCHK(h, hipFree(h->sf_stamps));
+    h->sf_stamps = nullptr;
+    drop_graphs(h);
+  }
+  return GPRX_OK;
+}
 #ifdef GPRX_PANEL_STAMPS
 int gprx_panel_stamps(unsigned long long* out64) {
   hipMemcpyFromSymbol(out64, HIP_SYMBOL(gprx::g_panel_stamps), sizeof(unsigned long long) * 64);

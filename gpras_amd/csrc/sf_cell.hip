@@ -1,5 +1,6 @@
 // Fused sparse evaluation (sgpr_fused.h): the one-workgroup-per-cell launches -- prep (Kuu, L, L^-1), mid (B, LB, c, the M x M gradient
 // algebra) and final (partials in chunk order -> the pinned result block) -- and the dispatch of the pass launchers by kernel id.
+#include "sgpr_asm.h"
 #include "sgpr_fused_dev.h"
 
 namespace gprx {
@@ -11,7 +12,7 @@ namespace gprx {
 // read, the cell's result words are cleared.
 template <int KID, int FORM>
 __global__ __launch_bounds__(256) void sf_prep_kernel(SfParams p, const double* __restrict__ par_src, const double* __restrict__ z_src,
-                                                      double* __restrict__ cpar_dst) {
+                                                      double* __restrict__ cpar_dst, SfAdam ad) {
   __shared__ __attribute__((aligned(16))) double sQ[NB * SF_LD];
   __shared__ __attribute__((aligned(16))) double sZ[NB * SF_DKP];
   __shared__ __attribute__((aligned(16))) double sIn[2 * NB * PSUB];
@@ -20,19 +21,49 @@ __global__ __launch_bounds__(256) void sf_prep_kernel(SfParams p, const double* 
   __shared__ double sPar[CELL_PAR];
   const int cell = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* A = p.arena + (int64_t)cell * p.ss;
+  if (p.active != nullptr && p.active[cell] == 0) return;
+  SF_STAMP(p, 0, 0)
+  // the parameter row and the inducing inputs come over the host link when the evaluation is host-driven: ONE round trip -- both
+  // requests go out before either is used; Z stays in LDS (raw, in the image that Kuu will take afterwards) for the staging passes
+  double* sZraw = sQ;  // [m][d] <= 64 x 64 doubles
+  static_assert(NB * (CELL_PAR - CELL_PAR_LS) <= NB * SF_LD, "the raw inducing inputs fit into the Kuu image");
+  const int nz = p.m * p.d;
+  const double* zsrc = z_src ? z_src + (int64_t)cell * nz : A + p.oZ;
+  double parv = 0.0;
+  if (ad.theta != nullptr) {
+    // resident optimiser: the row is formed here from the unconstrained variables (decode_theta of gprx.hip on the device: px_math.h
+    // gives the host's bits)
+    const double* th = ad.theta + (int64_t)cell * ad.nt;
+    if (tid == 0) parv = px_softplus(th[0]);
+    if (tid == 1) parv = NOISE_LOWER + px_softplus(th[ad.nt - 1]);
+    if (tid == 2) parv = (double)ad.units[cell];
+    if (tid == 3) parv = 1.0 / (NOISE_LOWER + px_softplus(th[ad.nt - 1]));
+    if (tid >= CELL_PAR_LS && tid < CELL_PAR_LS + p.d) parv = px_softplus(th[1 + (ad.ard ? tid - CELL_PAR_LS : 0)]);
+  } else if (tid < CELL_PAR) {
+    parv = par_src[(int64_t)cell * CELL_PAR + tid];
+  }
+  for (int e0 = 0; e0 < nz; e0 += 256 * 8) {
+    double zv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) zv[u] = zsrc[min(e0 + 256 * u + tid, nz - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u + tid;
+      if (e < nz) {
+        sZraw[e] = zv[u];
+        if (z_src) A[p.oZ + e] = zv[u];
+      }
+    }
+  }
   if (tid < CELL_PAR) {
-    const double v = par_src[(int64_t)cell * CELL_PAR + tid];
-    sPar[tid] = v;
-    cpar_dst[(int64_t)cell * CELL_PAR + tid] = v;
+    sPar[tid] = parv;
+    cpar_dst[(int64_t)cell * CELL_PAR + tid] = parv;
   }
   if (tid < p.cellres_stride) p.cellres[(int64_t)cell * p.cellres_stride + tid] = 0.0;
-  const double* zp = A + p.oZ;
-  if (z_src) {
-    zp = z_src + (int64_t)cell * p.m * p.d;
-    for (int e = tid; e < p.m * p.d; e += 256) A[p.oZ + e] = zp[e];
-  }
+  const double* zp = sZraw;
   exp_tab_fill(sTab);
   __syncthreads();
+  SF_STAMP(p, 0, 1)
   const double variance = sPar[0];
   const double* ls = sPar + CELL_PAR_LS;
   double r2[16], nb[16], na = 0.0;
@@ -59,8 +90,10 @@ __global__ __launch_bounds__(256) void sf_prep_kernel(SfParams p, const double* 
     sQ[lane * SF_LD + col] = q;
   }
   __syncthreads();
+  SF_STAMP(p, 0, 2)
   d4 acc[2][4];
   const int bad = sf_chain(sQ, SF_LD, sIn, sXb, acc, tid);
+  SF_STAMP(p, 0, 3)
   if (bad != 0 && tid == 0) atomicCAS(reinterpret_cast<int*>(p.cellres + (int64_t)cell * p.cellres_stride + 2), 0, bad);
   // L straight from the accumulators (16 lanes = one 128-byte line); L^-1 = (acc[1])^T through LDS
   const int g = lane >> 4, r = lane & 15;
@@ -75,6 +108,7 @@ __global__ __launch_bounds__(256) void sf_prep_kernel(SfParams p, const double* 
     }
   __syncthreads();
   sf_image_out(sQ, SF_LD, A + p.oLinv, tid);
+  SF_STAMP(p, 0, 4)
 }
 
 // ---- launch 3: one workgroup per cell ------------------------------------------------------------------------------------
@@ -95,54 +129,75 @@ __global__ __launch_bounds__(256) void sf_mid_kernel(SfParams p) {
   const double inv_s = par[3];
   double* A = p.arena + (int64_t)cell * p.ss;
   double* red = A + p.oRed;
+  if (p.active != nullptr && p.active[cell] == 0) return;
+  SF_STAMP(p, 64, 0)
+  load64(A + p.oLinv, sL, tid);  // (requested first: the loads travel under the slab sums)
   // S = sum over the chunks, in chunk order, of the three stored quadrants; B = I + S / s
   {
     const double* slab = A + p.oSlab;
-    // quadrant blocks of 32 x 32 = 1024 elements, three of them: 12 per thread, two neighbours per load
-    double s[6][2];
+    // the ten lower 16 x 16 tiles = 1280 pairs of neighbours: five per thread
+    double s[5][2];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) s[e][0] = s[e][1] = 0.0;
-    for (int c = 0; c < p.nchunks; ++c) {
-      const double* sc = slab + (int64_t)c * NB * NB;
+    for (int e = 0; e < 5; ++e) s[e][0] = s[e][1] = 0.0;
+    int soff[5], si[5], sj[5], sdiag_tile[5];
 #pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        const int q = tid + 256 * e;         // 1536 pairs: block = q / 512, inside: row = (q % 512) / 16, pair = q % 16
-        const int blk = q >> 9, row = (q & 511) >> 4, pr = q & 15;
-        const int i = (blk == 0 ? 0 : 32) + row, j = (blk == 2 ? 32 : 0) + 2 * pr;
-        const d2 v = *reinterpret_cast<const d2*>(sc + i * NB + j);
+    for (int e = 0; e < 5; ++e) {
+      const int q = tid + 256 * e;  // tile = q / 128 (row-major over the lower tiles), inside: row = (q % 128) / 8, pair = q % 8
+      const int t = q >> 7, row = (q & 127) >> 3, pr = q & 7;
+      const int rb = t < 1 ? 0 : (t < 3 ? 1 : (t < 6 ? 2 : 3)), cb = t - rb * (rb + 1) / 2;
+      si[e] = rb * 16 + row;
+      sj[e] = cb * 16 + 2 * pr;
+      sdiag_tile[e] = rb == cb;
+      soff[e] = si[e] * NB + sj[e];
+    }
+    // (eight chunks' loads in flight: a rolled loop over the chunks waits for each chunk's loads -- ~2 us each, the slabs come from other
+    // CUs' stores -- before it issues the next ones)
+    int c = 0;
+    for (; c + 8 <= p.nchunks; c += 8) {
+      d2 v[8][5];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) v[u][e] = *reinterpret_cast<const d2*>(slab + (int64_t)(c + u) * NB * NB + soff[e]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+          s[e][0] += v[u][e].x;
+          s[e][1] += v[u][e].y;
+        }
+    }
+    for (; c < p.nchunks; ++c) {
+#pragma unroll
+      for (int e = 0; e < 5; ++e) {
+        const d2 v = *reinterpret_cast<const d2*>(slab + (int64_t)c * NB * NB + soff[e]);
         s[e][0] += v.x;
         s[e][1] += v.y;
       }
     }
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      const int q = tid + 256 * e;
-      const int blk = q >> 9, row = (q & 511) >> 4, pr = q & 15;
-      const int i = (blk == 0 ? 0 : 32) + row, j = (blk == 2 ? 32 : 0) + 2 * pr;
+    for (int e = 0; e < 5; ++e) {
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
         const double sv = s[e][c2];
-        const int jj = j + c2;
+        const int i = si[e], jj = sj[e] + c2;
         const double bv = __builtin_fma(sv, inv_s, i == jj ? 1.0 : 0.0);
         sBf[i * SM_LD + jj] = bv;
-        if (blk == 1) sBf[jj * SM_LD + i] = bv;  // mirror of the lower-left quadrant
+        if (!sdiag_tile[e]) sBf[jj * SM_LD + i] = bv;  // mirror of a tile below the diagonal (diagonal tiles were computed whole)
         if (i == jj) sdiag[i] = sv * inv_s;
       }
     }
-    if (tid < NB) {
-      double u = 0.0;
-      for (int c = 0; c < p.nchunks; ++c) u += A[p.oU + (int64_t)c * NB + tid];
-      sb[tid] = u * inv_s;
-    }
+    if (tid < NB) sb[tid] = sf_sum_chunks(A + p.oU + tid, NB, p.nchunks) * inv_s;
   }
-  load64(A + p.oLinv, sL, tid);
   __syncthreads();
+  SF_STAMP(p, 64, 1)
   if (wave == 0) {  // tr(A A^T)
-    const double a = wave_sum(sdiag[lane]);
+    const double a = wave_sum_dpp(sdiag[lane]);
     if (lane == 0) red[2] = a;
   }
   d4 acc[2][4];
   const int bad = sf_chain(sBf, SM_LD, sC, sC + 2 * NB * PSUB, acc, tid);
+  SF_STAMP(p, 64, 2)
   if (bad != 0 && tid == 0) atomicCAS(reinterpret_cast<int*>(p.cellres + (int64_t)cell * p.cellres_stride + 2), 0, NB + bad);
   __syncthreads();
 #pragma unroll
@@ -172,51 +227,104 @@ __global__ __launch_bounds__(256) void sf_mid_kernel(SfParams p) {
   }
   __syncthreads();
   if (wave == 0) {
-    const double a = wave_sum(log(sdiag[lane]));
+    const double a = wave_sum_dpp(log(sdiag[lane]));
     double cq = sb[lane];
-    cq = wave_sum(cq * cq);
+    cq = wave_sum_dpp(cq * cq);
     if (lane == 0) {
       red[0] = a;
       red[1] = cq;
     }
   }
+  SF_STAMP(p, 64, 3)
   if (!p.want_grad) return;
-  // ---- gradient algebra (the sequence of sgpr.h sgpr_small_kernel) ----
-  for (int row = wave; row < NB; row += 4) {
-    const double v = sB[row * SM_LD + lane];
-    const double a = wave_sum(v * v);
-    if (lane == 0) srow[row] = a;
+  // ---- gradient algebra (sgpr.h sgpr_small_kernel's quantities) with the structure used: L^-1, LB^-1 and R are lower triangular, Sigma^-1,
+  // T1 and Q^-1 symmetric -- 120 MFMAs per wave instead of 320.  Work is dealt in 16 x 16 tiles with their k-block ranges (tables below).
+  {
+    double sq = 0.0;  // |LB^-1|_F^2: sixteen elements per thread, then the lanes, then the waves
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = tid + 256 * e;
+      const double v = sB[(q >> 6) * SM_LD + (q & 63)];
+      sq = __builtin_fma(v, v, sq);
+    }
+    sq = wave_sum_dpp(sq);
+    if (lane == 0) srow[wave] = sq;
   }
   trsv_t64(sB, sb, reinterpret_cast<double(*)[NB]>(part), tid);  // LB^-T c   (its barriers also publish srow)
-  if (wave == 0) {
-    const double a = wave_sum(srow[lane]);
-    if (lane == 0) red[3] = a;
-  }
+  if (tid == 0) red[3] = (srow[0] + srow[1]) + (srow[2] + srow[3]);
   trsv_t64(sL, sb, reinterpret_cast<double(*)[NB]>(part), tid);  // m = L^-T LB^-T c
   if (tid < NB) A[p.oM + tid] = sb[tid];
-  d4 accR[2][2], accS[2][2], accT[2][2], accQ[2][2];
-  mm64<false>(sB, sL, accR, wm, wn, g, r);  // R = LB^-1 L^-1
-  mm64_store(accR, sC, wm, wn, g, r);
-  __syncthreads();
-  mm64<true>(sC, sC, accS, wm, wn, g, r);   // Sigma^-1 = R^T R
-  __syncthreads();
-  mm64<false>(sBf, sL, accR, wm, wn, g, r);  // T2 = B L^-1
-  mm64_store(accR, sC, wm, wn, g, r);
-  __syncthreads();
-  mm64<true>(sL, sC, accT, wm, wn, g, r);   // T1 = L^-T T2
-  mm64<true>(sL, sL, accQ, wm, wn, g, r);   // Q^-1 = L^-T L^-1
+  SF_STAMP(p, 64, 4)
+  // one 16 x 16 tile of op(A) B over the k blocks [kb0, kb1): op(A)[i][k] = TA ? A[k][i] : A[i][k]
+  auto tile_mm = [&](auto ta, const double* __restrict__ sa, const double* __restrict__ sbm, int rt, int ct, int kb0, int kb1) {
+    constexpr bool TA = decltype(ta)::value;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    for (int kb = kb0; kb < kb1; ++kb) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+      for (int j = 0; j < 4; ++j) {
+        const int k = kb * 16 + 4 * g + j;
+        const double av = TA ? sa[k * SM_LD + rt * 16 + r] : sa[(rt * 16 + r) * SM_LD + k];
+        const double bv = sbm[k * SM_LD + ct * 16 + r];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+    }
+    return acc;
+  };
+  auto tile_store = [&](const d4& acc, double* __restrict__ dst, int rt, int ct) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int q = 0; q < 4; ++q) dst[(rt * 16 + g + 4 * q) * SM_LD + ct * 16 + r] = acc[q];
+  };
+  using std::false_type;
+  using std::true_type;
+  // lower tiles (rt << 2 | ct), four slots per wave, 0xff = none.  R: k blocks ct .. rt (20 in all, 5 per wave); the symmetric results:
+  // k blocks rt .. 3 (20 in all, 5 per wave)
+  constexpr unsigned char kTilesR[4][4] = {{0x30, 0x00, 0xff, 0xff}, {0x31, 0x10, 0xff, 0xff}, {0x20, 0x21, 0xff, 0xff}, {0x32, 0x11, 0x22, 0x33}};
+  constexpr unsigned char kTilesS[4][4] = {{0x00, 0x30, 0xff, 0xff}, {0x10, 0x20, 0xff, 0xff}, {0x11, 0x21, 0xff, 0xff}, {0x22, 0x31, 0x32, 0x33}};
+  // R = LB^-1 L^-1 (lower) -> sC
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int code = kTilesR[wave][sl];
+    if (code != 0xff) {
+      const int rt = code >> 4, ct = code & 15;
+      tile_store(tile_mm(false_type{}, sB, sL, rt, ct, ct, rt + 1), sC, rt, ct);
+    }
+  }
+  __syncthreads();
+  // Sigma^-1 = R^T R on the lower tiles (R[k][i] is zero for k < i: k blocks rt .. 3)
+  d4 accS[4], accT[4], accQ[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int code = kTilesS[wave][sl];
+    if (code != 0xff) accS[sl] = tile_mm(true_type{}, sC, sC, code >> 4, code & 15, code >> 4, 4);
+  }
+  __syncthreads();
+  // T2 = B L^-1 (all sixteen tiles: wave w = row block w; k blocks ct .. 3) -> sC
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) tile_store(tile_mm(false_type{}, sBf, sL, wave, ct, ct, 4), sC, wave, ct);
+  __syncthreads();
+  // T1 = L^-T T2 and Q^-1 = L^-T L^-1 on the lower tiles; W and G_Q written on both sides of the diagonal
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int code = kTilesS[wave][sl];
+    if (code != 0xff) {
+      const int rt = code >> 4, ct = code & 15;
+      accT[sl] = tile_mm(true_type{}, sL, sC, rt, ct, rt, 4);
+      accQ[sl] = tile_mm(true_type{}, sL, sL, rt, ct, rt, 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = wm * 32 + a * 16 + g + 4 * q, col = wn * 32 + b * 16 + r;
+        const int row = rt * 16 + g + 4 * q, col = ct * 16 + r;
         double w, gq;
-        sgpr_combine(accQ[a][b][q], accS[a][b][q], accT[a][b][q], sb[row], sb[col], w, gq);
+        sgpr_combine(accQ[sl][q], accS[sl][q], accT[sl][q], sb[row], sb[col], w, gq);
         A[p.oW + row * NB + col] = w;
         A[p.oGQ + row * NB + col] = gq;
+        if (rt != ct) {
+          A[p.oW + col * NB + row] = w;
+          A[p.oGQ + col * NB + row] = gq;
+        }
       }
+    }
+  }
+  SF_STAMP(p, 64, 5)
 }
 constexpr size_t SF_MID_SMEM = sizeof(double) * (4 * NB * SM_LD + NB + 4 * NB + NB + NB);
 static_assert(2 * 2 * NB * PSUB <= NB * SM_LD, "the chain's two sub-panel buffers fit into one 64 x 64 image");
@@ -225,39 +333,24 @@ static_assert(2 * 2 * NB * PSUB <= NB * SM_LD, "the chain's two sub-panel buffer
 // red_host (8 per cell): [0..3] from sf_mid, [4] |y - P^T m|^2.  sums_host (2 width per cell, width = 2 + d): the layout the host tail of
 // sgpr_objective_batch has always read: [0] sum G_P g, [2 + k] dELBO/dl_k through Kuf (isotropic: the total in [2]), then the same
 // for Kuu.  dz_host: (m, d) dELBO/dZ.
+// the sums of a cell's pass-2 partial blocks, in chunk order: red4 = |y - P^T m|^2, sums[2 width] (thread ranges [8, 8 + width) and
+// [128, 128 + width)); shared by the host-driven final launch and the resident optimiser's, so both see the same bits
 template <int ISO>
-__global__ __launch_bounds__(256) void sf_final_kernel(SfParams p, double* __restrict__ res_host, double* __restrict__ red_host,
-                                                       double* __restrict__ sums_host, double* __restrict__ dz_host) {
-  const int cell = blockIdx.x, tid = threadIdx.x;
-  const double* par = p.cpar + (int64_t)cell * CELL_PAR;
-  const double* ls = par + CELL_PAR_LS;
-  const double* A = p.arena + (int64_t)cell * p.ss;
-  const double* P2 = A + p.oP2;
+__device__ __forceinline__ void sf_reduce_sums(const SfParams& p, const double* __restrict__ P2, const double* __restrict__ ls, int tid,
+                                               double* __restrict__ red4, double* __restrict__ sums) {
   const int width = 2 + p.d;
-  if (tid < p.cellres_stride) res_host[(int64_t)cell * p.cellres_stride + tid] = p.cellres[(int64_t)cell * p.cellres_stride + tid];
-  if (tid < 4) red_host[(int64_t)cell * 8 + tid] = A[p.oRed + tid];
-  if (!p.want_grad) return;
-  if (tid == 4) {
-    double s = 0.0;
-    for (int c = 0; c < p.nchunks; ++c) s += P2[(int64_t)c * p.p2w + 2];
-    red_host[(int64_t)cell * 8 + 4] = s;
-  }
-  double* sums = sums_host + (int64_t)cell * 2 * width;
+  if (tid == 4) *red4 = sf_sum_chunks(P2 + 2, p.p2w, p.nchunks);
   if (tid >= 8 && tid < 8 + width) {  // through Kuf
     const int e = tid - 8;
     double v = 0.0;
     if (e == 0) {
-      for (int c = 0; c < p.nchunks; ++c) v += P2[(int64_t)c * p.p2w];
+      v = sf_sum_chunks(P2, p.p2w, p.nchunks);
     } else if (e >= 2) {
       const int k = e - 2;
       if (ISO) {
-        if (k == 0) {
-          for (int c = 0; c < p.nchunks; ++c) v += P2[(int64_t)c * p.p2w + 1];
-          v = -v / ls[0];
-        }
+        if (k == 0) v = -sf_sum_chunks(P2 + 1, p.p2w, p.nchunks) / ls[0];
       } else {
-        for (int c = 0; c < p.nchunks; ++c) v += P2[(int64_t)c * p.p2w + 4 + k];
-        v = -v / ls[k];
+        v = -sf_sum_chunks(P2 + 4 + k, p.p2w, p.nchunks) / ls[k];
       }
     }
     sums[e] = v;
@@ -278,14 +371,123 @@ __global__ __launch_bounds__(256) void sf_final_kernel(SfParams p, double* __res
     }
     sums[width + e] = v;
   }
-  for (int e = tid; e < p.m * p.d; e += 256) {
-    const int k = e % p.d;
-    double v = 0.0;
-    for (int c = 0; c <= p.nchunks; ++c) v += P2[(int64_t)c * p.p2w + SF_P2_HEAD + e];
-    dz_host[(int64_t)cell * p.m * p.d + e] = v / ls[k];
-  }
 }
 
+template <int ISO>
+__global__ __launch_bounds__(256) void sf_final_kernel(SfParams p, double* __restrict__ res_host, double* __restrict__ red_host,
+                                                       double* __restrict__ sums_host, double* __restrict__ dz_host) {
+  const int cell = blockIdx.x, tid = threadIdx.x;
+  const double* par = p.cpar + (int64_t)cell * CELL_PAR;
+  const double* ls = par + CELL_PAR_LS;
+  const double* A = p.arena + (int64_t)cell * p.ss;
+  const double* P2 = A + p.oP2;
+  const int width = 2 + p.d;
+  SF_STAMP(p, 128, 0)
+  if (tid < p.cellres_stride) res_host[(int64_t)cell * p.cellres_stride + tid] = p.cellres[(int64_t)cell * p.cellres_stride + tid];
+  if (tid < 4) red_host[(int64_t)cell * 8 + tid] = A[p.oRed + tid];
+  if (!p.want_grad) return;
+  sf_reduce_sums<ISO>(p, P2, ls, tid, red_host + (int64_t)cell * 8 + 4, sums_host + (int64_t)cell * 2 * width);
+  for (int e = tid; e < p.m * p.d; e += 256) {
+    const int k = e % p.d;
+    dz_host[(int64_t)cell * p.m * p.d + e] = sf_sum_chunks(P2 + SF_P2_HEAD + e, p.p2w, p.nchunks + 1) / ls[k];
+  }
+  SF_STAMP(p, 128, 1)
+}
+
+// ---- launch 5 of a step of the resident Adam loop ----------------------------------------------------------------------------
+// What sgpr_objective_batch's host tail, chain_rule, log_prior and gprx_adam_batch's host loop do for one cell and one step, in their
+// order and with their arithmetic (sgpr_asm.h): the same variables after every step, bit for bit.
+template <int ISO>
+__global__ __launch_bounds__(256) void sf_adam_kernel(SfParams p, SfAdam ad) {
+  __shared__ double shs[2 * (2 + CELL_PAR - CELL_PAR_LS)];
+  __shared__ double sred[8];
+  const int cell = blockIdx.x, tid = threadIdx.x;
+  if (ad.active[cell] == 0) return;
+  const double* par = p.cpar + (int64_t)cell * CELL_PAR;
+  const double* ls = par + CELL_PAR_LS;
+  double* A = p.arena + (int64_t)cell * p.ss;
+  const double* P2 = A + p.oP2;
+  const int width = 2 + p.d, nt = ad.nt, nz = p.m * p.d, gw = nt + nz;
+  int info = 0;
+  __builtin_memcpy(&info, p.cellres + (int64_t)cell * p.cellres_stride + 2, sizeof(int));
+  if (info != 0) {
+    // the matrix of this cell stopped being positive definite: the evaluation counts, nothing is updated, the call ends with GPRX_ENOTPD
+    if (tid == 0) {
+      atomicCAS(ad.error, 0, cell + 1);
+      ad.n_evals[cell] += 1;
+      ad.active[cell] = 0;
+      ad.loss[cell] = __builtin_nan("");
+    }
+    return;
+  }
+  if (tid < 4) sred[tid] = A[p.oRed + tid];
+  sf_reduce_sums<ISO>(p, P2, ls, tid, &sred[4], shs);
+  __syncthreads();
+  const double variance = par[0], noise = par[1];
+  const double nn = (double)p.n;
+  const int t = ad.tstep[cell] + 1;
+  const double alpha = ad.alpha[t];
+  double* th = ad.theta + (int64_t)cell * nt;
+  double* mom = ad.mom + (int64_t)cell * gw;
+  double* vel = ad.vel + (int64_t)cell * gw;
+  if (tid < nt) {
+    const int k = tid;
+    const double du = sgpr_asm_dparam(k, ad.nlen, ad.ard, p.d, width, nn, NB, variance, noise, sred, shs);
+    double u, w = th[k];
+    bool trainable;
+    if (k == 0) {
+      u = variance;
+      trainable = (ad.mask & ASM_TRAIN_VARIANCE) != 0;
+    } else if (k < nt - 1) {
+      u = ls[k - 1];
+      trainable = (ad.mask & ASM_TRAIN_LENGTHSCALE) != 0;
+    } else {
+      u = noise;
+      trainable = (ad.mask & ASM_TRAIN_NOISE) != 0;
+    }
+    const double ge = sgpr_asm_chain(du, u, w, trainable);
+    if (trainable) {
+      double mo = mom[k], ve = vel[k];
+      adam_element(ge, alpha, mo, ve, w);
+      mom[k] = mo;
+      vel[k] = ve;
+      th[k] = w;
+    }
+  }
+  if ((ad.mask & ASM_TRAIN_Z) != 0) {
+    for (int e = tid; e < nz; e += 256) {
+      const int k = e % p.d;
+      const double dzv = sf_sum_chunks(P2 + SF_P2_HEAD + e, p.p2w, p.nchunks + 1) / ls[k];
+      const double ge = -dzv;
+      double mo = mom[nt + e], ve = vel[nt + e], x = A[p.oZ + e];
+      adam_element(ge, alpha, mo, ve, x);
+      mom[nt + e] = mo;
+      vel[nt + e] = ve;
+      A[p.oZ + e] = x;
+    }
+  }
+  if (tid == 255) {  // (a thread with no hyperparameter of its own)
+    const double elbo = sgpr_asm_elbo(nn, ad.yy[ad.units[cell]], variance, noise, sred);
+    double lp = 0.0;
+    {
+#pragma clang fp contract(off)
+      if (ad.mask & ASM_TRAIN_VARIANCE) lp += px_ln_logpdf(variance);
+      if (ad.mask & ASM_TRAIN_LENGTHSCALE)
+        for (int k = 0; k < ad.nlen; ++k) lp += px_ln_logpdf(ls[k]);
+      if (ad.mask & ASM_TRAIN_NOISE) lp += px_ln_logpdf(noise);
+    }
+    const double loss = -(elbo + lp);
+    double best = ad.best[cell];
+    int stale = ad.stale[cell];
+    const bool keep = adam_keep_running(loss, best, stale);
+    ad.best[cell] = best;
+    ad.stale[cell] = stale;
+    ad.loss[cell] = loss;
+    ad.n_evals[cell] += 1;
+    ad.tstep[cell] = t;
+    if (!keep || t >= ad.max_iter) ad.active[cell] = 0;
+  }
+}
 
 #define SF_KID_SWITCH(kid, MACRO) \
   switch (kid) {                  \
@@ -298,10 +500,12 @@ __global__ __launch_bounds__(256) void sf_final_kernel(SfParams p, double* __res
   }
 
 hipError_t sf_launch_prep(hipStream_t st, int kid, int form, const SfParams& p, int cells, const double* par_src, const double* z_src,
-                          double* cpar_dst) {
-#define SF_CASE(K_)                                                                                               \
-  if (form) hipLaunchKernelGGL((sf_prep_kernel<K_, 1>), dim3(cells), dim3(256), 0, st, p, par_src, z_src, cpar_dst); \
-  else hipLaunchKernelGGL((sf_prep_kernel<K_, 0>), dim3(cells), dim3(256), 0, st, p, par_src, z_src, cpar_dst);
+                          double* cpar_dst, const SfAdam* adam) {
+  SfAdam ad{};
+  if (adam) ad = *adam;
+#define SF_CASE(K_)                                                                                                   \
+  if (form) hipLaunchKernelGGL((sf_prep_kernel<K_, 1>), dim3(cells), dim3(256), 0, st, p, par_src, z_src, cpar_dst, ad); \
+  else hipLaunchKernelGGL((sf_prep_kernel<K_, 0>), dim3(cells), dim3(256), 0, st, p, par_src, z_src, cpar_dst, ad);
   SF_KID_SWITCH(kid, SF_CASE)
 #undef SF_CASE
   return hipGetLastError();
@@ -322,6 +526,12 @@ hipError_t sf_launch_final(hipStream_t st, int iso, const SfParams& p, int cells
                            double* dz_host) {
   if (iso) hipLaunchKernelGGL((sf_final_kernel<1>), dim3(cells), dim3(256), 0, st, p, res_host, red_host, sums_host, dz_host);
   else hipLaunchKernelGGL((sf_final_kernel<0>), dim3(cells), dim3(256), 0, st, p, res_host, red_host, sums_host, dz_host);
+  return hipGetLastError();
+}
+
+hipError_t sf_launch_adam(hipStream_t st, int iso, const SfParams& p, int cells, const SfAdam& adam) {
+  if (iso) hipLaunchKernelGGL((sf_adam_kernel<1>), dim3(cells), dim3(256), 0, st, p, adam);
+  else hipLaunchKernelGGL((sf_adam_kernel<0>), dim3(cells), dim3(256), 0, st, p, adam);
   return hipGetLastError();
 }
 

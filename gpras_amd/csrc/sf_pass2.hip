@@ -14,21 +14,27 @@ namespace gprx {
 // Partial block of a workgroup (p2w doubles): [0] sum w g, [1] sum w v h r2 (ISO), [2] sum (y - P^T m)^2, [4 + k] sum w v h ds_k^2,
 // [SF_P2_HEAD + i d + k] sum_j w v h ds_k  -- all UNSCALED by the lengthscales; the Kuu workgroup stores its dZ sums doubled
 // (G_Q is symmetric: both index positions of z_i contribute).
+// 512 threads = 8 waves (two per SIMD, see sf_pass1.hip).  Row-lane layout: lane = inducing point, wave w = columns 8 w .. 8 w + 7;
+// MFMA layout: wave w owns row block w >> 1 (16 rows) and the column blocks 2 (w & 1), 2 (w & 1) + 1 of W P.
 // Registers: what crosses the MFMA product per element is ONE value (v h; isotropic: also r2) -- sum w g is formed in the MFMA layout
 // as sum (W P) o P + sum_j y_j (P^T m)_j, so g dies with the store of P.
-template <int KID, int FORM, int ISO, int NKC>
-__global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParams p) {
-  constexpr int DZN = NKC == 1 ? SF_DK : 4 * SF_DK;  // dimensions this lane accumulates dK/dZ for
+constexpr int SF_NT = 512;
+constexpr int SF_NC = 8;  // columns per lane in the row-lane layout
+
+template <int KID, int FORM, int ISO, int NP>
+__global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
+  constexpr int NKC = NP > 0 ? 1 : 0;
+  constexpr int DZN = NP > 0 ? 2 * NP : 4 * SF_DK;  // dimensions this lane accumulates dK/dZ for
   __shared__ __attribute__((aligned(16))) double sPA[NB * SF_LD];  // the tile of Kuf, then W P in its place; at the end the dZ exchange
   __shared__ __attribute__((aligned(16))) double sZ[NB * SF_DKP];
   __shared__ __attribute__((aligned(16))) double sXc[NB * SF_DKP];
   __shared__ double sY[NB], sM[NB];
-  __shared__ double sQp[4][NB];
-  __shared__ double sRed[4][4];
-  static_assert(4 * NB * SF_DK <= NB * SF_LD, "the dZ exchange of one chunk of dimensions fits into the tile image");
+  __shared__ double sQp[8][NB];
+  __shared__ double sRed[8][4];
+  static_assert(4 * NB * SF_DK <= NB * SF_LD, "the dZ exchange of four waves and one chunk of dimensions fits into the tile image");
   const int cell = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, r = lane & 15;
-  const bool isq = chunk == p.nchunks;
+  if (p.active != nullptr && p.active[cell] == 0) return;  // (uniform over the workgroup)
   const double* par = p.cpar + (int64_t)cell * CELL_PAR;
   const double* ls = par + CELL_PAR_LS;
   const double variance = par[0], inv_s = par[3];
@@ -36,19 +42,26 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
   double* A = p.arena + (int64_t)cell * p.ss;
   const double* zp = A + p.oZ;
   const double* yp = p.Y + (int64_t)unit * p.np;
+  SF_STAMP(p, 96, 0)
+  // The Kuu part of a cell is a workgroup of its own (chunk index nchunks) while every workgroup of the launch finds a CU at once; beyond
+  // that (q_appended) the workgroup of the cell's last chunk takes it as a second part -- 16 cells x 17 workgroups on 256 CUs ran the
+  // seventeenth ones as a second round (73 against 54 us).  Either way the same code fills partial block nchunks: same values.
+  const int nparts = (p.q_appended && chunk == p.nchunks - 1) ? 2 : 1;
+  for (int part = 0; part < nparts; ++part) {
+  const bool isq = p.q_appended ? part == 1 : chunk == p.nchunks;
   const double* colpts = isq ? zp : p.X;
   const int ncolpts = isq ? p.m : p.n;
-  double fw[2][4][4];  // W as MFMA A-operand fragments (Kuf workgroups)
+  const int ntiles = isq ? 1 : min(SF_TILES, (p.np - chunk * SF_CHUNK) / NB);
+  double raw[NB * SF_DK / SF_NT];
+  sf_stage_fetch<SF_NT>(colpts, isq ? 0 : chunk * SF_CHUNK, ncolpts, p.d, 0, raw, tid);  // the first tile's points, before anything else
+  double fw[4][4];  // W as MFMA A-operand fragments: rows 16 wm + r, k = 16 ks + 4 g + j (Kuf workgroups)
   if (!isq) {
-    const double* W = A + p.oW;
+    const double* W = A + p.oW + (wm * 16 + r) * NB + 4 * g;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double* src = W + (wm * 32 + a * 16 + r) * NB + ks * 16 + 4 * g;
-        const d2 lo = *reinterpret_cast<const d2*>(src), hi = *reinterpret_cast<const d2*>(src + 2);
-        fw[a][ks][0] = lo.x; fw[a][ks][1] = lo.y; fw[a][ks][2] = hi.x; fw[a][ks][3] = hi.y;
-      }
+    for (int ks = 0; ks < 4; ++ks) {
+      const d2 lo = *reinterpret_cast<const d2*>(W + ks * 16), hi = *reinterpret_cast<const d2*>(W + ks * 16 + 2);
+      fw[ks][0] = lo.x; fw[ks][1] = lo.y; fw[ks][2] = hi.x; fw[ks][3] = hi.y;
+    }
     if (tid < NB) sM[tid] = A[p.oM + tid];
   }
   const double mrow = isq ? 0.0 : A[p.oM + lane];
@@ -58,26 +71,33 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
   for (int k = 0; k < DZN; ++k) dz[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < (ISO ? 1 : DZN); ++k) lsk[k] = 0.0;
-  if constexpr (NKC == 1) sf_stage<FORM>(zp, 0, p.m, p.d, 0, ls, sZ, tid);  // (published by the first tile's staging barrier)
-  const int ntiles = isq ? 1 : min(SF_TILES, (p.np - chunk * SF_CHUNK) / NB);
+  if constexpr (NKC == 1) sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, 0, ls, sZ, tid);  // (published by the first tile's staging barrier)
+  SF_STAMP(p, 96, 1)
   for (int t = 0; t < ntiles; ++t) {
     const int j0 = isq ? 0 : chunk * SF_CHUNK + t * NB;
-    double r2[16], nb[16], na = 0.0;
+    double r2[SF_NC], nb[SF_NC], na = 0.0;
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) r2[jj] = nb[jj] = 0.0;
+    for (int jj = 0; jj < SF_NC; ++jj) r2[jj] = nb[jj] = 0.0;
     for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
       __syncthreads();
-      if constexpr (NKC != 1) sf_stage<FORM>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
-      sf_stage<FORM>(colpts, j0, ncolpts, p.d, k0, ls, sXc, tid);
-      if (k0 == 0 && tid < NB) sY[tid] = isq ? 0.0 : yp[j0 + tid];
+      if constexpr (NKC != 1) sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
+      if (k0 == 0) {
+        sf_stage_put<FORM, SF_NT>(raw, j0, ncolpts, p.d, 0, ls, sXc, tid);
+        if (tid < NB) sY[tid] = isq ? 0.0 : yp[j0 + tid];
+      } else {
+        sf_stage<FORM, SF_NT>(colpts, j0, ncolpts, p.d, k0, ls, sXc, tid);
+      }
       __syncthreads();
-      sf_r2_chunk<FORM>(sZ, sXc, lane, wave, min(SF_DK, p.d - k0), r2, na, nb);
+      if (k0 == 0 && t + 1 < ntiles) sf_stage_fetch<SF_NT>(colpts, j0 + NB, ncolpts, p.d, 0, raw, tid);  // the next tile's points travel from here on
+      if (t == 0 && k0 == 0) { SF_STAMP(p, 96, 2) }
+      sf_r2_chunk<FORM, SF_NC, NP>(sZ, sXc, lane, wave, min(SF_DK, p.d - k0), r2, na, nb);
     }
+    if (t == 0) { SF_STAMP(p, 96, 3) }
     // per element: g (Kuf workgroups: into the P tile, then dead), vh = v h, and for the isotropic lengthscale r2 stays
-    double wh[16];  // v h now, w v h once the weights are known
+    double wh[SF_NC];  // v h now, w v h once the weights are known
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const int col = wave * 16 + jj;
+    for (int jj = 0; jj < SF_NC; ++jj) {
+      const int col = wave * SF_NC + jj;
       double rr = r2[jj];
       if constexpr (FORM != 0) rr = expanded_r2(na, nb[jj], rr);
       r2[jj] = rr;
@@ -93,14 +113,12 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
         wh[jj] = wq * wh[jj];
       }
     }
+    if (t == 0) { SF_STAMP(p, 96, 4) }
     if (!isq) {
       __syncthreads();
       // W P on MFMA; P^T m by columns
-      d4 acc[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+      d4 acc[2];
+      acc[0] = acc[1] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         double fb[2][4];
@@ -111,34 +129,29 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fw[a][ks][j], fb[b][j], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fw[ks][j], fb[b][j], acc[b], 0, 0, 0);
       }
       {
-        const int col = tid & 63, qq = tid >> 6;
+        const int col = tid & 63, oct = tid >> 6;
         double sum = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum = __builtin_fma(sPA[(16 * qq + i) * SF_LD + col], sM[16 * qq + i], sum);
-        sQp[qq][col] = sum;
+        for (int i = 0; i < 8; ++i) sum = __builtin_fma(sPA[(8 * oct + i) * SF_LD + col], sM[8 * oct + i], sum);
+        sQp[oct][col] = sum;
       }
       // sum (W P) o P in the MFMA layout (P is zero wherever an element is masked)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sg = __builtin_fma(acc[a][b][q], sPA[(wm * 32 + a * 16 + g + 4 * q) * SF_LD + wn * 32 + b * 16 + r], sg);
+        for (int q = 0; q < 4; ++q) sg = __builtin_fma(acc[b][q], sPA[(wm * 16 + g + 4 * q) * SF_LD + wn * 32 + b * 16 + r], sg);
+      if (t == 0) { SF_STAMP(p, 96, 5) }
       __syncthreads();  // every wave has read P
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sPA[(wm * 32 + a * 16 + g + 4 * q) * SF_LD + wn * 32 + b * 16 + r] = acc[a][b][q];
+        for (int q = 0; q < 4; ++q) sPA[(wm * 16 + g + 4 * q) * SF_LD + wn * 32 + b * 16 + r] = acc[b][q];
       __syncthreads();
       if (tid < NB) {
-        const double qv = ((sQp[0][tid] + sQp[1][tid]) + sQp[2][tid]) + sQp[3][tid];
+        const double qv = ((sQp[0][tid] + sQp[1][tid]) + (sQp[2][tid] + sQp[3][tid])) + ((sQp[4][tid] + sQp[5][tid]) + (sQp[6][tid] + sQp[7][tid]));
         const bool live = j0 + tid < p.n;
         const double rv = live ? sY[tid] - qv : 0.0;
         resid = __builtin_fma(rv, rv, resid);
@@ -146,8 +159,8 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
       }
       // w v h with w = G_P = (W P + m y^T) / s
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int col = wave * 16 + jj;
+      for (int jj = 0; jj < SF_NC; ++jj) {
+        const int col = wave * SF_NC + jj;
         double wv = inv_s * sPA[lane * SF_LD + col];
         wv = __builtin_fma(inv_s * mrow, sY[col], wv);
         wh[jj] = (lane < p.m && j0 + col < p.n) ? wv * wh[jj] : 0.0;
@@ -155,53 +168,91 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
     }
     if constexpr (ISO != 0) {
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) siso = __builtin_fma(wh[jj], r2[jj], siso);
+      for (int jj = 0; jj < SF_NC; ++jj) siso = __builtin_fma(wh[jj], r2[jj], siso);
     }
+    if (t == 0) { SF_STAMP(p, 96, 6) }
     // per-dimension sums: dK/dZ (in this lane: its own inducing point) and, anisotropic, dK/dl_k
     for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
       if constexpr (NKC != 1) {
         if (p.d > SF_DK) {  // more than one chunk of dimensions: the staged coordinates of this chunk again
           __syncthreads();
-          sf_stage<FORM>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
-          sf_stage<FORM>(colpts, j0, ncolpts, p.d, k0, ls, sXc, tid);
+          sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
+          sf_stage<FORM, SF_NT>(colpts, j0, ncolpts, p.d, k0, ls, sXc, tid);
           __syncthreads();
         }
       }
       const int dk = min(SF_DK, p.d - k0);
       const int kc = NKC == 1 ? 0 : k0 / SF_DK;
+      // one pair of dimensions: dK/dZ sums (and, anisotropic, dK/dl_k) of this lane against its wave's columns
+      auto grad_pair = [&](auto kbase_c, const d2& zv, const d2 (&xv)[SF_NC]) {
+        constexpr int KB = decltype(kbase_c)::value;
 #pragma unroll
-      for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {  // (static accumulator indices: one guarded block is taken)
-        if (kcs == kc) {
-#pragma unroll
-        for (int kk = 0; kk < SF_DK; kk += 2) {
-          if (kk < dk) {
-          const d2 zv = *reinterpret_cast<const d2*>(sZ + lane * SF_DKP + kk);
-#pragma unroll
-          for (int jj = 0; jj < 16; ++jj) {
-            const d2 xv = *reinterpret_cast<const d2*>(sXc + (wave * 16 + jj) * SF_DKP + kk);
-            const double d0 = zv.x - xv.x, d1 = zv.y - xv.y;
-            if constexpr (ISO != 0) {
-              dz[kcs * SF_DK + kk] = __builtin_fma(wh[jj], d0, dz[kcs * SF_DK + kk]);
-              dz[kcs * SF_DK + kk + 1] = __builtin_fma(wh[jj], d1, dz[kcs * SF_DK + kk + 1]);
-            } else {
-              const double t0 = wh[jj] * d0, t1 = wh[jj] * d1;
-              dz[kcs * SF_DK + kk] += t0;
-              dz[kcs * SF_DK + kk + 1] += t1;
-              lsk[kcs * SF_DK + kk] = __builtin_fma(t0, d0, lsk[kcs * SF_DK + kk]);
-              lsk[kcs * SF_DK + kk + 1] = __builtin_fma(t1, d1, lsk[kcs * SF_DK + kk + 1]);
-            }
-          }
+        for (int jj = 0; jj < SF_NC; ++jj) {
+          const double d0 = zv.x - xv[jj].x, d1 = zv.y - xv[jj].y;
+          if constexpr (ISO != 0) {
+            dz[KB] = __builtin_fma(wh[jj], d0, dz[KB]);
+            dz[KB + 1] = __builtin_fma(wh[jj], d1, dz[KB + 1]);
+          } else {
+            const double t0 = wh[jj] * d0, t1 = wh[jj] * d1;
+            dz[KB] += t0;
+            dz[KB + 1] += t1;
+            lsk[KB] = __builtin_fma(t0, d0, lsk[KB]);
+            lsk[KB + 1] = __builtin_fma(t1, d1, lsk[KB + 1]);
           }
         }
+      };
+      if constexpr (NP > 0) {
+        // software-pipelined as sf_r2_chunk: the reads of pair p + 1 under the arithmetic of pair p
+        d2 za, zb, xa[SF_NC], xb[SF_NC];
+        sf_load_pair<SF_NC>(sZ, sXc, lane, wave, 0, za, xa);
+        auto step2 = [&](auto pp_c) {
+          constexpr int PP = decltype(pp_c)::value;
+          if constexpr (PP < NP) {
+            if constexpr (PP + 1 < NP) sf_load_pair<SF_NC>(sZ, sXc, lane, wave, 2 * (PP + 1), zb, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            grad_pair(std::integral_constant<int, 2 * PP>{}, za, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PP + 2 < NP) sf_load_pair<SF_NC>(sZ, sXc, lane, wave, 2 * (PP + 2), za, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PP + 1 < NP) grad_pair(std::integral_constant<int, 2 * (PP + 1)>{}, zb, xb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        step2(std::integral_constant<int, 0>{});
+        step2(std::integral_constant<int, 2>{});
+        step2(std::integral_constant<int, 4>{});
+        step2(std::integral_constant<int, 6>{});
+      } else {
+#pragma unroll
+        for (int kcs = 0; kcs < 4; ++kcs) {  // (static accumulator indices: one guarded block is taken)
+          if (kcs == kc) {
+#pragma unroll
+            for (int kk = 0; kk < SF_DK; kk += 2) {
+              if (kk < dk) {
+                d2 zv, xv[SF_NC];
+                sf_load_pair<SF_NC>(sZ, sXc, lane, wave, kk, zv, xv);
+                auto call = [&](auto kb) { grad_pair(kb, zv, xv); };
+                // (kcs and kk are unrolled constants, but not constant expressions: dispatch on the 32 possible bases)
+                const int kbv = kcs * SF_DK + kk;
+#define SF_GP(K_) if (kbv == K_) call(std::integral_constant<int, K_>{});
+                SF_GP(0) SF_GP(2) SF_GP(4) SF_GP(6) SF_GP(8) SF_GP(10) SF_GP(12) SF_GP(14) SF_GP(16) SF_GP(18) SF_GP(20) SF_GP(22) SF_GP(24) SF_GP(26)
+                SF_GP(28) SF_GP(30) SF_GP(32) SF_GP(34) SF_GP(36) SF_GP(38) SF_GP(40) SF_GP(42) SF_GP(44) SF_GP(46) SF_GP(48) SF_GP(50) SF_GP(52)
+                SF_GP(54) SF_GP(56) SF_GP(58) SF_GP(60) SF_GP(62)
+#undef SF_GP
+              }
+            }
+          }
         }
       }
     }
+    if (t == 0) { SF_STAMP(p, 96, 7) }
   }
+  SF_STAMP(p, 96, 8)
   // ---- this workgroup's partial block ----
-  double* out = A + p.oP2 + (int64_t)chunk * p.p2w;
+  double* out = A + p.oP2 + (int64_t)(isq ? p.nchunks : chunk) * p.p2w;
   {
     // (Kuf workgroups: sg so far is sum (W P) o P + sum y (P^T m), i.e. s v times sum G_P g)
-    const double a = wave_sum(sg), b = wave_sum(siso), c = wave_sum(resid);
+    const double a = wave_sum_dpp(sg), b = wave_sum_dpp(siso), c = wave_sum_dpp(resid);
     if (lane == 0) {
       sRed[wave][0] = a;
       sRed[wave][1] = b;
@@ -210,61 +261,82 @@ __global__ __launch_bounds__(256, NKC == 1 ? 2 : 1) void sf_pass2_kernel(SfParam
   }
   __syncthreads();
   if (tid < 3) {
-    double v = ((sRed[0][tid] + sRed[1][tid]) + sRed[2][tid]) + sRed[3][tid];
+    double v = ((sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid])) + ((sRed[4][tid] + sRed[5][tid]) + (sRed[6][tid] + sRed[7][tid]));
     if (tid == 0 && !isq) v = v * inv_s / variance;
     out[tid] = v;
   }
+  // dZ: the eight waves' sums of every (row, dimension), four waves at a time through the tile image
   double* sEx = sPA;  // [4 waves][64 rows][16]
   for (int kc = 0; kc * SF_DK < p.d; ++kc) {
-    __syncthreads();
+    double part[2] = {0.0, 0.0};  // this thread's two (row, dimension) entries: e = tid, tid + 512
 #pragma unroll
-    for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
-      if (kcs == kc) {
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((wave >> 2) == half) {
 #pragma unroll
-        for (int kk = 0; kk < SF_DK; ++kk) sEx[(wave * NB + lane) * SF_DK + kk] = dz[kcs * SF_DK + kk];
+        for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
+          if (kcs == kc) {
+#pragma unroll
+            for (int kk = 0; kk < SF_DK; ++kk) sEx[((wave & 3) * NB + lane) * SF_DK + kk] = kcs * SF_DK + kk < DZN ? dz[(kcs * SF_DK + kk) % DZN] : 0.0;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15;
+        const double v = ((sEx[(0 * NB + i) * SF_DK + kk] + sEx[(1 * NB + i) * SF_DK + kk]) + sEx[(2 * NB + i) * SF_DK + kk]) + sEx[(3 * NB + i) * SF_DK + kk];
+        part[u] = half == 0 ? v : part[u] + v;
       }
     }
-    __syncthreads();
-    for (int e = tid; e < NB * SF_DK; e += 256) {
-      const int i = e >> 4, kk = e & 15, k = kc * SF_DK + kk;
-      if (k < p.d) {
-        const double v = ((sEx[(0 * NB + i) * SF_DK + kk] + sEx[(1 * NB + i) * SF_DK + kk]) + sEx[(2 * NB + i) * SF_DK + kk]) + sEx[(3 * NB + i) * SF_DK + kk];
-        out[SF_P2_HEAD + i * p.d + k] = isq ? 2.0 * v : v;
-      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15, k = kc * SF_DK + kk;
+      if (k < p.d) out[SF_P2_HEAD + i * p.d + k] = isq ? 2.0 * part[u] : part[u];
     }
     if constexpr (ISO == 0) {
-      // dK/dl_k: sum over the 64 rows (lanes) and the 4 waves
+      // dK/dl_k: sum over the 64 rows (lanes) and the 8 waves
       __syncthreads();
 #pragma unroll
       for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
         if (kcs == kc) {
 #pragma unroll
           for (int kk = 0; kk < SF_DK; ++kk) {
-            const double a = wave_sum(lsk[kcs * SF_DK + kk]);
-            if (lane == 0) sEx[wave * SF_DK + kk] = a;
+            if (kcs * SF_DK + kk < DZN) {
+              const double a = wave_sum_dpp(lsk[(kcs * SF_DK + kk) % DZN]);
+              if (lane == 0) sEx[wave * SF_DK + kk] = a;
+            }
           }
         }
       }
       __syncthreads();
-      if (tid < SF_DK && kc * SF_DK + tid < p.d)
-        out[4 + kc * SF_DK + tid] = ((sEx[tid] + sEx[SF_DK + tid]) + sEx[2 * SF_DK + tid]) + sEx[3 * SF_DK + tid];
+      if (tid < SF_DK && kc * SF_DK + tid < p.d) {
+        double v = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += sEx[w8 * SF_DK + tid];
+        out[4 + kc * SF_DK + tid] = v;
+      }
     }
   }
+  }  // part
+  SF_STAMP(p, 96, 9)
 }
 
 hipError_t SF_CAT(sf_launch_pass2_kid, SF_KID)(hipStream_t st, int form, int iso, const SfParams& p, int cells) {
-  const dim3 grid(p.nchunks + 1, cells), block(256);
-  const bool one = p.d <= SF_DK;
+  const dim3 grid(p.nchunks + (p.q_appended ? 0 : 1), cells), block(SF_NT);
+  const int np = p.d <= 12 ? 6 : (p.d <= SF_DK ? 8 : 0);
+#define SF_P2(F_, I_)                                                                                \
+  if (np == 6) hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, F_, I_, 6>), grid, block, 0, st, p);      \
+  else if (np == 8) hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, F_, I_, 8>), grid, block, 0, st, p); \
+  else hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, F_, I_, 0>), grid, block, 0, st, p);
   if (form) {
-    if (one) hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, 1, 0, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, 1, 0, 0>), grid, block, 0, st, p);
+    SF_P2(1, 0)
   } else if (iso) {
-    if (one) hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, 0, 1, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, 0, 1, 0>), grid, block, 0, st, p);
+    SF_P2(0, 1)
   } else {
-    if (one) hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, 0, 0, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, 0, 0, 0>), grid, block, 0, st, p);
+    SF_P2(0, 0)
   }
+#undef SF_P2
   return hipGetLastError();
 }
 

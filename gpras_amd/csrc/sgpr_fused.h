@@ -49,14 +49,44 @@ struct SfParams {
   double* cellres;     // per cell CELL_RES doubles; [2] carries the pivot status as an int
   int cellres_stride;  // doubles
   int want_grad;
+  const int* active;   // device-resident optimiser: per cell 0 = this cell has stopped (every launch returns at once for it); null: all run
+  int q_appended;      // launch 4: the Kuu part runs in the workgroup of the cell's last chunk instead of a workgroup of its own
+  unsigned long long* stamps;  // development aid: null, or SF_STAMP_WORDS words that workgroup (0, 0) fills with s_memtime at its phase boundaries
 };
+// Device-resident Adam (gpr.py:147-173 for every cell of a batch): the optimiser's state lives in device memory, a step is the five
+// launches with sf_adam_kernel as the fifth, the host looks at the stop flags every few steps only.
+struct SfAdam {
+  double* theta;      // (cells, nt) unconstrained variables [variance, lengthscales .., noise]; Z lives in the cell blocks (oZ)
+  double* mom;        // (cells, nt + m d) first moments  [theta | Z]
+  double* vel;        // (cells, nt + m d) second moments
+  double* best;       // (cells) best loss so far
+  double* loss;       // (cells) loss of the last evaluation
+  int* stale;         // (cells) steps without an improvement of more than tol
+  int* active;        // (cells) 1 while the cell runs
+  int* n_evals;       // (cells) evaluations taken part in
+  int* tstep;         // (cells) steps done
+  const int* units;   // (cells) output column of each cell
+  const double* alpha;  // [0 .. max_iter]: lr sqrt(1 - beta2^t) / (1 - beta1^t), formed on the host (pow)
+  const double* yy;   // (units) y.y
+  int* error;         // [0]: 0, or 1 + the first cell whose Kuu or B stopped being positive definite
+  int nt, nlen, ard, mask, max_iter;
+};
+
+constexpr int SF_STAMP_WORDS = 5 * 32;  // prep | pass 1 | mid | pass 2 | final, 32 words each ([31] of each block: s_memrealtime at entry, 100 MHz)
+#define SF_STAMP(p_, base_, i_)                                                                                   \
+  if ((p_).stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                         \
+    (p_).stamps[(base_) + (i_)] = __builtin_amdgcn_s_memtime();                                                   \
+    if ((i_) == 0) (p_).stamps[(base_) + 31] = __builtin_amdgcn_s_memrealtime();                                  \
+  }
 
 // ---- launchers (defined in sf_cell.hip, sf_pass1.hip, sf_pass2.hip; the pass kernels are compiled once per kernel id, -DSF_KID=k,
 // so that the translation units build in parallel) ------------------------------------------------------------------------------
 // par_src: `cells` rows of CELL_PAR doubles (pinned host memory or device memory); z_src: (cells, m, d) inducing inputs, or nullptr when
 // the cell blocks already hold Z; cpar_dst: the device parameter table the other launches read.
 hipError_t sf_launch_prep(hipStream_t st, int kid, int form, const SfParams& p, int cells, const double* par_src, const double* z_src,
-                          double* cpar_dst);
+                          double* cpar_dst, const SfAdam* adam = nullptr);
+// fifth launch of a step of the resident Adam loop: partial sums in chunk order, loss, gradient, update, stop rule
+hipError_t sf_launch_adam(hipStream_t st, int iso, const SfParams& p, int cells, const SfAdam& adam);
 hipError_t sf_launch_pass1(hipStream_t st, int kid, int form, const SfParams& p, int cells);
 hipError_t sf_launch_mid(hipStream_t st, const SfParams& p, int cells);
 hipError_t sf_launch_pass2(hipStream_t st, int kid, int form, int iso, const SfParams& p, int cells);
