@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--cells", type=int, default=CELLS_PER_STEP, help="independent cells per GPU per step")
     ap.add_argument("--no-extras", action="store_true", help="skip F2/F3/predict/cpu legs (profiling runs)")
     ap.add_argument("--batched-only", action="store_true", help="profiling runs: no single-cell calls either, so every launch in a trace belongs to a batched step")
+    ap.add_argument("--only-sparse", action="store_true", help="run only the sparse-model legs (sparse_section) and print their JSON")
     ap.add_argument("--only-c4", action="store_true", help="of the secondary legs run only configs[3] (C4: every rank predicts its share, one gather to rank 0)")
     ap.add_argument("--c4-cells", type=int, default=1250, help="cells per rank in the C4 leg (configs[3]: 10 000 cells over 8 GPUs)")
     ap.add_argument("--c4-points", type=int, default=N_TEST, help="test points per cell in the C4 leg")
@@ -137,8 +138,111 @@ def mapped_runtimes():
     return sorted(libs)
 
 
+def sparse_section(device, extra):
+    """The sparse-model legs of the bench (rank 0, N = 1): fills extra["sparse_sgpr"] and the flat keys earlier rounds reported."""
+    from gpras_amd.gpr import GPRAS
+    from gpras_amd.synth import make_regression
+
+    # ---- the sparse model: what gpras actually fits (SGPR behind gpr.py:299; hot loop gpr.py:147-173; sizes of the sweep in
+    # production/analysis/cross_validation.py:100-126: modes 1..50, M 1..300) -- N = 4096, d = 10 ----
+    # M <= 64 runs the five-launch evaluation of sgpr_fused.h and the Adam loop resident on the device; larger M the general launch
+    # sequence with the host-stepped loop.  flops per evaluation of the loss alone: 2 M^2 N + 2 M^3 / 3 (SURVEY 8d).
+    n_s, d_s = 4096, 10
+    sp = {"shape": {"n_train": n_s, "d": d_s}, "by_M": {}}
+    xs50, ys50, xt50 = make_regression(n_s, d_s, n_outputs=50, n_test=100000, config=6, unit=1)
+    xs50, ys50 = xs50.astype(np.float64), ys50.astype(np.float64)
+
+    def sgpr_rates(m_s, modes, reps):
+        g_ = GPRAS("RBF", device=device)
+        g_._init_models(xs50, ys50[:, :modes], m_s, "grid")
+        u_ = np.arange(modes, dtype=np.int32)
+        th_ = np.stack([mm.theta() for mm in g_.models])
+        z_ = np.stack([mm.Z for mm in g_.models])
+        for _ in range(3):  # (first evaluation eager, second captures the launch graph, third replays it)
+            g_.engine.objective_batch(u_, th_, 15, True, zs=z_)
+        t1_ = time.perf_counter()
+        for _ in range(reps):
+            g_.engine.objective_batch(u_, th_, 15, True, zs=z_)
+        dt_ = (time.perf_counter() - t1_) / reps
+        del g_
+        return modes / dt_
+
+    for m_s, launches in ((50, 5), (128, None), (300, None)):
+        flops_eval = 2.0 * m_s * m_s * n_s + 2.0 * m_s ** 3 / 3.0
+        row = {"loss_flops_per_evaluation": flops_eval,
+               "launches_per_evaluation": launches if launches else "general launch sequence (M > 64): ~45 and growing with M / 64"}
+        for modes in (1, 16, 50):
+            r = sgpr_rates(m_s, modes, 40 if m_s == 50 else 6)
+            row[f"loss_grad_evals_per_s_{modes}_modes"] = r
+            row[f"loss_tflops_{modes}_modes"] = r * flops_eval / 1e12
+        sp["by_M"][str(m_s)] = row
+    extra["sgpr_n4096_d10_m50_loss_grad_evals_per_s"] = sp["by_M"]["50"]["loss_grad_evals_per_s_1_modes"]
+    extra["sgpr_batched16_loss_grad_evals_per_s"] = sp["by_M"]["50"]["loss_grad_evals_per_s_16_modes"]
+    # the reference's default fit: k-means Z, two-stage Adam 100 + 100 (gpr.py:112-127), all modes in lock step
+    for modes in (1, 16, 50):
+        best_fit = np.inf
+        for _ in range(3):
+            g_ = GPRAS("RBF", device=device)
+            t1 = time.perf_counter()
+            g_.fit(xs50, ys50[:, :modes], 50, "kmeans", "two-stage")
+            best_fit = min(best_fit, time.perf_counter() - t1)
+            evals_ = int(sum(mm.n_evals for mm in g_.models))
+            if modes != 50:
+                del g_
+        sp[f"two_stage_fit_seconds_{modes}_modes_M50"] = best_fit
+        sp[f"two_stage_fit_evaluations_{modes}_modes_M50"] = evals_
+    extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = sp["two_stage_fit_seconds_1_modes_M50"]
+    extra["sgpr_16_modes_two_stage_fit_seconds_lockstep"] = sp["two_stage_fit_seconds_16_modes_M50"]
+    extra["sgpr_units_per_s_lockstep"] = 16 / sp["two_stage_fit_seconds_16_modes_M50"]
+    # sparse predict (gpr.py:336-339): 50 fitted modes at N* = 100 000 points through GPRAS.predict (host arrays in, host arrays out)
+    g_.predict(xt50[:4096])
+    t1 = time.perf_counter()
+    pm_, pv_ = g_.predict(xt50)
+    tp_ = time.perf_counter() - t1
+    sp["predict_50_modes_M50_n_test_100000"] = {"seconds_host_to_host": tp_, "points_per_s_all_modes": 50 * xt50.shape[0] / tp_, "finite": bool(np.all(np.isfinite(pm_)) and np.all(pv_ > 0))}
+    del g_
+    # a long Adam run, the cross-validation's regime (max_iter 5 000 - 10 000 there): 5 000 steps on all variables, 16 modes, M = 50;
+    # the early stop (patience 50 at 1e-5 relative improvement) may end modes sooner -- evaluations are reported
+    g_ = GPRAS("RBF", device=device)
+    t1 = time.perf_counter()
+    g_.fit(xs50, ys50[:, :16], 50, "kmeans", "adam", max_iter=5000)
+    ta_ = time.perf_counter() - t1
+    ev_ = [int(mm.n_evals) for mm in g_.models]
+    sp["adam_5000_steps_16_modes_M50"] = {"seconds": ta_, "evaluations_per_mode_min_max": [min(ev_), max(ev_)], "evaluations_per_s": sum(ev_) / ta_,
+                                          "microseconds_per_lockstep_step": 1e6 * ta_ / max(ev_)}
+    del g_
+    # the same for M = 128 (host-stepped loop over the general launch sequence), 200 steps
+    g_ = GPRAS("RBF", device=device)
+    t1 = time.perf_counter()
+    g_.fit(xs50, ys50[:, :16], 128, "kmeans", "adam", max_iter=200)
+    ta_ = time.perf_counter() - t1
+    ev_ = [int(mm.n_evals) for mm in g_.models]
+    sp["adam_200_steps_16_modes_M128"] = {"seconds": ta_, "evaluations_per_s": sum(ev_) / ta_, "microseconds_per_lockstep_step": 1e6 * ta_ / max(ev_)}
+    del g_
+    extra["sparse_sgpr"] = sp
+    # for comparison the older scheme, one engine + host thread per mode (workers=8)
+    xs16, ys16 = xs50, ys50[:, :16]
+    m_s = 50
+    g8 = GPRAS("RBF", device=device)
+    t1 = time.perf_counter()
+    g8.fit(xs16, ys16, m_s, "kmeans", "two-stage", workers=8)
+    t8 = time.perf_counter() - t1
+    extra["sgpr_16_modes_two_stage_fit_seconds_workers8"] = t8
+    extra["sgpr_units_per_s_workers8"] = 16 / t8
+    extra["sgpr_loss_grad_evals_per_s_workers8"] = sum(m.n_evals for m in g8.models) / t8
+    del g8
+
+
 def main():
     args = parse_args()
+    if args.only_sparse:  # development aid: the sparse legs alone, one JSON object
+        from gpras_amd import _build
+
+        _build.build()
+        extra = {}
+        sparse_section(0, extra)
+        print(json.dumps(extra))
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
     # RCCL and the HIP runtime print banners to stdout: keep stdout for the one JSON line only
@@ -558,50 +662,7 @@ def main():
             extra["F3_lockstep_fits_per_s"] = 16 / t16
             extra["F3_lockstep_evaluations"] = int(sum(m.n_evals for m in g16.models))
             del g16
-            # sparse model at a reference-realistic size (gpras example config: 10 modes, 50 inducing points; gpr.py:299):
-            # SGPR.training_loss + gradient evaluations, and the reference's default fit (two-stage Adam, 100 + 100 steps)
-            n_s, d_s, m_s = 4096, 10, 50
-            xsp, ysp, _ = make_regression(n_s, d_s, n_outputs=1, n_test=0, config=6, unit=0)
-            gs = GPRAS("RBF", device=device)
-            gs._init_models(xsp, ysp, m_s, "kmeans")
-            ms_model = gs.models[0]
-            for _ in range(3):  # (the first evaluation of a shape runs eagerly, the second captures the launch graph, the third replays it)
-                ms_model.loss_and_grad()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                ms_model.loss_and_grad()
-            extra["sgpr_n4096_d10_m50_loss_grad_evals_per_s"] = 50 / (time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            gs.fit(xsp, ysp, m_s, "kmeans", "two-stage")
-            extra["sgpr_n4096_d10_m50_two_stage_fit_seconds"] = time.perf_counter() - t1
-            # the sparse path is launch-latency bound (~45 dependent launches per evaluation): all modes go through the SAME
-            # launches (gprx_objective_batch, cell index in every grid) -- 16 cells per call, then the default two-stage fit
-            # of 16 modes in lock step; for comparison the older scheme, one engine + host thread per mode (workers=8)
-            xs16, ys16, _ = make_regression(n_s, d_s, n_outputs=16, n_test=0, config=6, unit=1)
-            g16s = GPRAS("RBF", device=device)
-            g16s._init_models(xs16.astype(np.float64), ys16.astype(np.float64), m_s, "kmeans")
-            u16 = np.arange(16, dtype=np.int32)
-            th16 = np.stack([mm.theta() for mm in g16s.models])
-            z16 = np.stack([mm.Z for mm in g16s.models])
-            g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
-            t1 = time.perf_counter()
-            for _ in range(20):
-                g16s.engine.objective_batch(u16, th16, 15, True, zs=z16)
-            extra["sgpr_batched16_loss_grad_evals_per_s"] = 20 * 16 / (time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            g16s.fit(xs16, ys16, m_s, "kmeans", "two-stage")
-            tl = time.perf_counter() - t1
-            extra["sgpr_16_modes_two_stage_fit_seconds_lockstep"] = tl
-            extra["sgpr_units_per_s_lockstep"] = 16 / tl
-            del g16s
-            g8 = GPRAS("RBF", device=device)
-            t1 = time.perf_counter()
-            g8.fit(xs16, ys16, m_s, "kmeans", "two-stage", workers=8)
-            t8 = time.perf_counter() - t1
-            extra["sgpr_16_modes_two_stage_fit_seconds_workers8"] = t8
-            extra["sgpr_units_per_s_workers8"] = 16 / t8
-            extra["sgpr_loss_grad_evals_per_s_workers8"] = sum(m.n_evals for m in g8.models) / t8
-            del g8
+            sparse_section(device, extra)
             # the other sizes of the target: N = 1024 (batched cells) and BASELINE configs[4], N = 16384 d = 12 (one cell alone)
             sizes = {}
             c1 = 512  # smaller matrices need more cells per launch to fill the chip

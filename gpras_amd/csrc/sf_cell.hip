@@ -387,9 +387,20 @@ __global__ __launch_bounds__(256) void sf_final_kernel(SfParams p, double* __res
   if (tid < 4) red_host[(int64_t)cell * 8 + tid] = A[p.oRed + tid];
   if (!p.want_grad) return;
   sf_reduce_sums<ISO>(p, P2, ls, tid, red_host + (int64_t)cell * 8 + 4, sums_host + (int64_t)cell * 2 * width);
-  for (int e = tid; e < p.m * p.d; e += 256) {
-    const int k = e % p.d;
-    dz_host[(int64_t)cell * p.m * p.d + e] = sf_sum_chunks(P2 + SF_P2_HEAD + e, p.p2w, p.nchunks + 1) / ls[k];
+  {
+    const int nz = p.m * p.d;
+    for (int e0 = 0; e0 < nz; e0 += 256 * 4) {  // four outputs per thread at once: 32 loads in flight
+      int off[4];
+      double acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) off[u] = SF_P2_HEAD + min(e0 + 256 * u + tid, nz - 1);
+      sf_sum_chunks_n<4>(P2, off, p.p2w, p.nchunks + 1, acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 256 * u + tid;
+        if (e < nz) dz_host[(int64_t)cell * nz + e] = acc[u] / ls[e % p.d];
+      }
+    }
   }
   SF_STAMP(p, 128, 1)
 }
@@ -455,15 +466,29 @@ __global__ __launch_bounds__(256) void sf_adam_kernel(SfParams p, SfAdam ad) {
     }
   }
   if ((ad.mask & ASM_TRAIN_Z) != 0) {
-    for (int e = tid; e < nz; e += 256) {
-      const int k = e % p.d;
-      const double dzv = sf_sum_chunks(P2 + SF_P2_HEAD + e, p.p2w, p.nchunks + 1) / ls[k];
-      const double ge = -dzv;
-      double mo = mom[nt + e], ve = vel[nt + e], x = A[p.oZ + e];
-      adam_element(ge, alpha, mo, ve, x);
-      mom[nt + e] = mo;
-      vel[nt + e] = ve;
-      A[p.oZ + e] = x;
+    for (int e0 = 0; e0 < nz; e0 += 256 * 4) {  // four elements per thread at once: their 32 + 12 loads in flight together
+      int off[4];
+      double acc[4], mo[4], ve[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + 256 * u + tid, nz - 1);
+        off[u] = SF_P2_HEAD + e;
+        mo[u] = mom[nt + e];
+        ve[u] = vel[nt + e];
+        x[u] = A[p.oZ + e];
+      }
+      sf_sum_chunks_n<4>(P2, off, p.p2w, p.nchunks + 1, acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 256 * u + tid;
+        if (e < nz) {
+          const double ge = -(acc[u] / ls[e % p.d]);
+          adam_element(ge, alpha, mo[u], ve[u], x[u]);
+          mom[nt + e] = mo[u];
+          vel[nt + e] = ve[u];
+          A[p.oZ + e] = x[u];
+        }
+      }
     }
   }
   if (tid == 255) {  // (a thread with no hyperparameter of its own)

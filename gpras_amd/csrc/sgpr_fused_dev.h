@@ -193,6 +193,38 @@ __device__ __forceinline__ double sf_sum_chunks(const double* __restrict__ src, 
   return acc;
 }
 
+// the same for NE outputs of one thread at once (offsets off[u]; clamped duplicates for outputs a thread does not have): NE x 8 loads in
+// flight per batch.  Each output's additions are exactly sf_sum_chunks's.
+template <int NE>
+__device__ __forceinline__ void sf_sum_chunks_n(const double* __restrict__ src, const int (&off)[NE], int64_t stride, int count, double (&acc)[NE]) {
+#pragma unroll
+  for (int u = 0; u < NE; ++u) acc[u] = 0.0;
+  int c = 0;
+  for (; c + 8 <= count; c += 8) {
+    double t[NE][8];
+#pragma unroll
+    for (int u = 0; u < NE; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[u][k] = src[(int64_t)(c + k) * stride + off[u]];
+#pragma unroll
+    for (int u = 0; u < NE; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[u] += t[u][k];
+  }
+  if (c < count) {
+    double t[NE][8];
+#pragma unroll
+    for (int u = 0; u < NE; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[u][k] = src[(int64_t)min(c + k, count - 1) * stride + off[u]];
+#pragma unroll
+    for (int u = 0; u < NE; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c + k < count) acc[u] += t[u][k];
+  }
+}
+
 // ---- the 64 x 64 chain: Cholesky factor and its inverse in one workgroup ------------------------------------------------------
 // sImg: the symmetric matrix (lower triangle read), row stride ld.  On return acc[0] holds L, acc[1] holds L^-T, both in the MFMA C
 // layout of tile_ops.h chain_step (wave w: rows 16 w .. 16 w + 15).  Returns the 1-based failing pivot or 0.

@@ -101,6 +101,12 @@ class GPRAS:
         can_lockstep = len(models) > 1 and len(self.engines) == 1 and hasattr(self.engine, "objective_batch")
         if lockstep and not can_lockstep:
             raise ValueError("lockstep fitting needs several modes on one engine (workers=1)")
+        if len(models) == 1 and len(self.engines) == 1 and lockstep is None and optimization_method in BATCHED_OPTIMIZERS and hasattr(self.engine, "adam_batch"):
+            # one mode with an Adam-based driver: the loop inside the library as well (sparse models with M <= 64: resident on the
+            # device, no host round trip per step); same variables as the serial driver bit for bit (tests/test_gpu_gpras.py)
+            stats1: dict[str, int] = {"batches": 0}
+            BATCHED_OPTIMIZERS[optimization_method](models, stats=stats1, **opt_kwargs)
+            return
         if can_lockstep and (lockstep is None or lockstep):
             # modes per batched launch sequence: 32, or fewer when the per-cell workspaces (kernel matrix, L^-1 and K^-1 of
             # an exact model: 5 N^2 doubles) would not fit into the free device memory

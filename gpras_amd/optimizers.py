@@ -232,7 +232,7 @@ class _PackedBatch:
     @staticmethod
     def usable(models) -> bool:
         m0 = models[0]
-        return (len(models) > 1 and hasattr(m0.backend, "objective_batch") and all(m.backend is m0.backend and m.mask == m0.mask for m in models)
+        return (len(models) >= 1 and hasattr(m0.backend, "objective_batch") and all(m.backend is m0.backend and m.mask == m0.mask for m in models)
                 and all((m.Z is None) == (m0.Z is None) for m in models))
 
     def assign(self, rows, x_rows):

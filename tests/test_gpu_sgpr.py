@@ -346,3 +346,33 @@ def test_fused_evaluation_agrees_with_the_launch_sequence_and_does_not_depend_on
             assert np.max(np.abs(g1[0] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref)))
     finally:
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("kernel,ard", [("RBF", False), ("Matern52", True)])
+def test_sgpr_at_the_top_of_the_references_sweep_m300(lib, kernel, ard):
+    """M = 300 inducing points -- the upper end of the reference's cross-validation sweep (production/analysis/cross_validation.py:108,
+    data_models.py:114-119) -- takes the general launch sequence (M > 64): loss 1e-9, gradient 1e-7 against the oracle, batch = single."""
+    n, d, m, cells = 1500, 10, 300, 3
+    x, y, _ = make_regression(n, d, n_outputs=cells, n_test=0, config=3, unit=300)
+    rng = np.random.default_rng(300)
+    h = make_handle(lib, n, d, m, kernel, ard, x, y)
+    nt = 2 + (d if ard else 1)
+    try:
+        zs = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] + 1e-2 * rng.standard_normal((m, d)) for _ in range(cells)]))
+        thetas = np.ascontiguousarray(rng.normal(0.1, 0.2, size=(cells, nt)))
+        units = np.arange(cells, dtype=np.int32)
+        losses, grads = np.zeros(cells), np.zeros((cells, nt + m * d))
+        check(lib.gprx_objective_batch(h, cells, ptr(units), ptr(thetas), ptr(zs), 15, ptr(losses), ptr(grads)), h)
+        for c in range(cells):
+            th, zc = np.ascontiguousarray(thetas[c]), np.ascontiguousarray(zs[c])
+            wl = th[1:-1] if ard else float(th[1])
+            ref_loss, g = osg.loss_and_grad(kernel, x, y[:, c], zc, float(th[0]), wl, float(th[-1]))
+            ref = np.concatenate([[g["variance"]], np.atleast_1d(g["lengthscales"]), [g["noise"]], np.asarray(g["Z"]).ravel()])
+            assert abs(losses[c] - ref_loss) <= 1e-9 * abs(ref_loss)
+            assert np.max(np.abs(grads[c][:nt] - ref[:nt])) <= 1e-7 * max(1.0, np.max(np.abs(ref[:nt])))
+            assert np.max(np.abs(grads[c][nt:] - ref[nt:])) <= 1e-7 * max(1.0, np.max(np.abs(ref[nt:])))
+        single, g1 = C.c_double(), np.zeros(nt + m * d)
+        check(lib.gprx_objective(h, 1, ptr(np.ascontiguousarray(thetas[1])), ptr(np.ascontiguousarray(zs[1])), 15, C.byref(single), ptr(g1)), h)
+        assert single.value == losses[1] and np.array_equal(g1, grads[1])
+    finally:
+        lib.gprx_destroy(h)
