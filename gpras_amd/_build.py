@@ -20,7 +20,7 @@ LIB_PATH = PKG_DIR / "libgprx.so"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # (object name, source, extra defines)
 UNITS = (
-    [("gprx", "gprx.hip", []), ("sf_cell", "sf_cell.hip", [])]
+    [("gprx", "gprx.hip", []), ("sf_cell", "sf_cell.hip", []), ("sf_adam", "sf_adam.hip", [])]
     + [(f"sf_pass1_k{k}", "sf_pass1.hip", [f"-DSF_KID={k}"]) for k in range(5)]
     + [(f"sf_pass2_k{k}", "sf_pass2.hip", [f"-DSF_KID={k}"]) for k in range(5)]
 )

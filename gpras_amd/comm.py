@@ -138,11 +138,13 @@ def rendezvous_cleanup(prefix: str, rank: int, success: bool) -> None:
     """Remove this rank's rendezvous files.  After a SUCCESSFUL collective initialisation every rank has read everything: ready, ack
     and (rank 0) the id go.  After a failure the ready file stays -- another rank may still have to read the status in it, and it is
     stamped with this launch's pid + time, so no later launch can take it for its own -- while the ack and the id, which nobody may
-    act on any more, go."""
-    _rm(f"{prefix}.ack.{rank}")
+    act on any more, go.  The ack stays after a failure too: a slower rank may still be between publishing its own ack and
+    reading the others'; with this rank's ack gone it would time out after ``timeout_s`` with "the ranks did not agree" instead of raising
+    the shared error that names the failing rank.  The ack carries the launch tag, so a later launch cannot mistake it."""
     if rank == 0:
         _rm(f"{prefix}.id")
     if success:
+        _rm(f"{prefix}.ack.{rank}")
         _rm(f"{prefix}.ready.{rank}")
 
 

@@ -1157,22 +1157,26 @@ SgprLayout sgpr_batch_layout(gprx_handle h) {
     o += round_up(doubles, 64);
     return at;
   };
+  // (the five-launch evaluation of sgpr_fused.h never stores Kuf, A', W Kuf or the weighted derivative: the four M x N matrices and the
+  // trace partials of the launch sequence shrink to nothing -- 8.4 of 9.9 MB per cell at M = 50, N = 4096, which a fit allocated and cleared)
+  const bool fused = mp == NB && h->sgpr_fused != 0;
+  const int64_t big = fused ? 0 : mp * np;
   L.oZ = take(m * d);
   L.oY = take(np);
-  L.oP = take(mp * np);
-  L.oAm = take(mp * np);
+  L.oP = take(big);
+  L.oAm = take(big);
   L.oQm = take(mp * mp);
   L.oBm = take((mp + NB) * mp);
   L.oInvDL = take(mp * NB);
   L.oInvDB = take(mp * NB);
   L.oSM = take((int64_t)SM_COUNT * mp * mp);
-  L.oWP = take(mp * np);
-  L.oWHP = take(mp * np);
+  L.oWP = take(big);
+  L.oWHP = take(big);
   L.oWHQ = take(mp * mp);
   L.oVecs = take(4 * mp + np);
   L.odZ = take(m * d);
   L.oStage = take(mp * STAGE_LD);
-  L.oPart = take(L.part_p + L.part_q + 2 * L.width);
+  L.oPart = take(fused ? 0 : L.part_p + L.part_q + 2 * L.width);
   L.oWs = take((int64_t)L.nsplit * mp * mp);
   L.oRed = take(8);
   L.oKs = take(mp * SGPR_PRED_TILE);                                           // batched predict: Kus tile of this cell
@@ -1467,7 +1471,10 @@ int sgpr_objective_batch(gprx_handle h, int count, const int* units, const Theta
   static const bool no_graph = getenv("GPRX_NO_GRAPH") != nullptr;  // escape hatch: eager launches
   const bool want_grad = g != nullptr;
   bool replayed = false;
-  if (!no_graph && !h->sgraph_off && !h->profiling) {
+  // (the five launches of the fused evaluation go out eagerly: replaying them from a graph starts the first kernel later than a direct
+  // launch does -- 178.8 against 172.5 us per 16-cell evaluation, MI355X_MICROARCH.md "graph-replay-floor")
+  const bool five_launches = mp == NB && h->sgpr_fused != 0;
+  if (!no_graph && !h->sgraph_off && !h->profiling && !five_launches) {
     const std::pair<int, int> key(count, want_grad ? 1 : 0);
     auto it = h->sgraphs.find(key);
     if (it == h->sgraphs.end()) {
@@ -1583,9 +1590,9 @@ int sgpr_predict_batch(gprx_handle h, int count, const double* xs_dev, int64_t n
   return GPRX_OK;
 }
 
-// gprx_adam_batch for sparse models with M <= 64: the loop RESIDENT on the device.  A step is five launches (sgpr_fused.h: prep with the
-// positive transforms evaluated on the device, pass 1, mid, pass 2, sf_adam_kernel = partial sums + loss + gradient + Keras's update + the
-// stop rule of gpr.py:160-171); cells that have stopped return at once from every launch.  The host enqueues `check_every` steps, then reads
+// gprx_adam_batch for sparse models with M <= 64: the loop RESIDENT on the device.  A step is FOUR launches (sgpr_fused.h: pass 1, mid,
+// pass 2, and sf_adam_prep_kernel = partial sums + loss + gradient + Keras's update + the stop rule of gpr.py:160-171, then Kuu, L, L^-1
+// of the updated variables with the positive transforms evaluated on the device); cells that have stopped return at once from every launch.  The host enqueues `check_every` steps, then reads
 // the stop flags (count + 1 ints through pinned memory) -- no gradient, loss or parameter crosses the host link during the run (round 4:
 // every step synchronised, downloaded the gradients, updated on the host and uploaded).  Same variables as the host-stepped loop, bit
 // for bit (sgpr_asm.h, px_math.h; tests/test_gpu_gpras.py).  A cell whose Kuu or B stops being positive definite ends the call with
@@ -1668,14 +1675,14 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   int error_cell = 0;
   h->factorized = false;  // the cell blocks are overwritten
   h->sparse_view = false;
+  HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, nullptr, nullptr, h->cellpar.p, &ad));  // opens step 1
   for (int done = 0; done < max_iter;) {
     const int k = std::min(check_every, max_iter - done);
     for (int i = 0; i < k; ++i) {
-      HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, nullptr, nullptr, h->cellpar.p, &ad));
       HIPCHK(h, sf_launch_pass1(st, h->kid, h->dist_form, p, count));
       HIPCHK(h, sf_launch_mid(st, p, count));
       HIPCHK(h, sf_launch_pass2(st, h->kid, h->dist_form, iso, p, count));
-      HIPCHK(h, sf_launch_adam(st, iso, p, count, ad));
+      HIPCHK(h, sf_launch_adam_prep(st, h->kid, h->dist_form, iso, p, count, ad, h->cellpar.p));  // closes this step, opens the next
     }
     done += k;
     HIPCHK(h, hipMemcpyAsync(flags, ad.active, sizeof(int) * count, hipMemcpyDeviceToHost, st));
@@ -3352,8 +3359,14 @@ int gprx_set_tuning(const char* key, int value) {
 
 int gprx_set_handle_tuning(gprx_handle h, const char* key, int value) {
   if (!h || !key) return fail(h, GPRX_EINVAL, "null argument");
+  const int fused_before = h->sgpr_fused;
   if (!apply_tuning(h->tune, h->predict_path, h->sgpr_fused, key, value)) return fail(h, GPRX_EINVAL, "unknown tuning key or bad value");
   if (hipSetDevice(h->device) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) drop_graphs(h);  // captured with the old schedule
+  if (h->sgpr_fused != fused_before) {  // the cell blocks of the two sparse schedules differ (sgpr_batch_layout): the arena is rebuilt on the next call
+    h->sarena_slots = 0;
+    h->factorized = h->sparse_view ? false : h->factorized;
+    h->sparse_view = false;
+  }
   return GPRX_OK;
 }
 

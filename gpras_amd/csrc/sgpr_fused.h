@@ -85,8 +85,10 @@ constexpr int SF_STAMP_WORDS = 5 * 32;  // prep | pass 1 | mid | pass 2 | final,
 // the cell blocks already hold Z; cpar_dst: the device parameter table the other launches read.
 hipError_t sf_launch_prep(hipStream_t st, int kid, int form, const SfParams& p, int cells, const double* par_src, const double* z_src,
                           double* cpar_dst, const SfAdam* adam = nullptr);
-// fifth launch of a step of the resident Adam loop: partial sums in chunk order, loss, gradient, update, stop rule
-hipError_t sf_launch_adam(hipStream_t st, int iso, const SfParams& p, int cells, const SfAdam& adam);
+// The launch between two steps of the resident Adam loop (sf_adam.hip): partial sums in chunk order, loss, gradient, update, stop rule of
+// step t, then -- for cells that keep running -- Kuu, L, L^-1 of the new variables (the prep of step t + 1).  A step is FOUR launches:
+// pass 1, mid, pass 2, this one; sf_launch_prep opens the first step.
+hipError_t sf_launch_adam_prep(hipStream_t st, int kid, int form, int iso, const SfParams& p, int cells, const SfAdam& adam, double* cpar_dst);
 hipError_t sf_launch_pass1(hipStream_t st, int kid, int form, const SfParams& p, int cells);
 hipError_t sf_launch_mid(hipStream_t st, const SfParams& p, int cells);
 hipError_t sf_launch_pass2(hipStream_t st, int kid, int form, int iso, const SfParams& p, int cells);

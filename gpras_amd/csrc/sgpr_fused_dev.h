@@ -229,7 +229,9 @@ __device__ __forceinline__ void sf_sum_chunks_n(const double* __restrict__ src, 
 // sImg: the symmetric matrix (lower triangle read), row stride ld.  On return acc[0] holds L, acc[1] holds L^-T, both in the MFMA C
 // layout of tile_ops.h chain_step (wave w: rows 16 w .. 16 w + 15).  Returns the 1-based failing pivot or 0.
 __device__ __forceinline__ int sf_chain(const double* __restrict__ sImg, int ld, double* __restrict__ sIn, double* __restrict__ sX, d4 (&acc)[2][4],
-                                        int tid) {
+                                        int tid, unsigned long long* stamps = nullptr) {
+#define SF_CHAIN_STAMP(i_) \
+  if (stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[8 + (i_)] = __builtin_amdgcn_s_memtime();
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
@@ -248,14 +250,24 @@ __device__ __forceinline__ int sf_chain(const double* __restrict__ sImg, int ld,
   c.g = g;
   c.r = r;
   c.bad = 0;
+  SF_CHAIN_STAMP(0)
   chain_step<0>(acc, c);
+  SF_CHAIN_STAMP(1)
   chain_step<1>(acc, c);
+  SF_CHAIN_STAMP(2)
   chain_step<2>(acc, c);
+  SF_CHAIN_STAMP(3)
   chain_step<3>(acc, c);
+  SF_CHAIN_STAMP(4)
   chain_step<4>(acc, c);
+  SF_CHAIN_STAMP(5)
   chain_step<5>(acc, c);
+  SF_CHAIN_STAMP(6)
   chain_step<6>(acc, c);
+  SF_CHAIN_STAMP(7)
   chain_step<7>(acc, c);
+  SF_CHAIN_STAMP(8)
+#undef SF_CHAIN_STAMP
   return c.bad;
 }
 

@@ -95,11 +95,13 @@ class Engine:
             raise ValueError(f"theta must have {self.n_theta} entries")
         zk, zp = self._z_ptr(z)
         loss = C.c_double()
-        if want_grad and self.m != 0 and self.d <= 64:
-            # a sparse model's evaluation with its gradient -- every step of a first-order or L-BFGS driver -- goes through the batched
-            # launches with ONE cell (round 4): 21 launches replayed from a graph instead of ~40 launches and a dozen copies, 0.22 against
-            # 0.40 ms at N = 4096, M = 50; the values are gprx_objective's bit for bit (tests/test_gpu_sgpr.py).  The handle's single-model
-            # state is not touched: predict factorises at the final parameters anyway (GPModel.predict).
+        if want_grad and self.m > 64 and self.d <= 64:
+            # a sparse model with M > 64 inducing points: its evaluation with the gradient goes through the batched launches with ONE cell
+            # (round 4): the launch sequence replayed from a graph instead of ~40 launches and a dozen copies; the values are
+            # gprx_objective's bit for bit (tests/test_gpu_sgpr.py).  NOTE: this route leaves NO resident factorisation -- ``predict``
+            # after it raises (GPRX_ESTATE: "gprx_predict before a successful gprx_factorize / gprx_objective"); call
+            # ``objective(..., want_grad=False)`` (= gprx_factorize) first, as GPModel.predict does.  M <= 64 (round 5) takes
+            # gprx_objective below: the five-launch evaluation of sgpr_fused.h, which keeps the factorisation in cell block 0 for predict.
             losses = np.full(1, np.nan)
             grad = np.full((1, self.n_theta + self.m * self.d), np.nan)
             units = np.array([unit], dtype=np.int32)
@@ -206,7 +208,9 @@ class Engine:
 
     @_locked
     def predict(self, xs, include_noise: bool = True):
-        """Mean and variance at ``xs`` for the unit factorised by the last ``objective`` call."""
+        """Mean and variance at ``xs`` for the unit factorised by the last ``objective`` call -- any call for exact models and for
+        sparse models with M <= 64; for sparse models with M > 64 only a call with ``want_grad=False`` (the gradient route of those goes
+        through a one-cell batch that keeps no resident factorisation: a ``RuntimeError`` naming gprx_factorize says so)."""
         xs = as_f64(xs)
         if xs.ndim != 2 or xs.shape[1] != self.d:
             raise ValueError(f"x must be (N*, {self.d})")

@@ -253,3 +253,32 @@ def test_wait_hands_over_to_stream_synchronize_and_the_next_call_is_clean(lib):
     finally:
         lib.gprx_set_tuning(b"wait_handover_us", 200000)
         lib.gprx_destroy(h)
+
+
+@pytest.mark.parametrize("m", [40, 100])
+def test_engine_objective_with_gradient_then_predict(lib, m):
+    """Engine.objective(want_grad=True) followed by Engine.predict either works (M <= 64: the fused evaluation keeps the
+    factorisation in cell block 0) or raises a clear error (M > 64: the one-cell batch keeps none), never a stale prediction."""
+    from gpras_amd.engine import Engine
+
+    n, d = 600, 4
+    x, y, xs = make_regression(n, d, n_outputs=2, n_test=9, config=5, unit=m)
+    rng = np.random.default_rng(m)
+    z = np.ascontiguousarray(x[rng.choice(n, size=m, replace=False)] + 0.01 * rng.standard_normal((m, d)))
+    theta = theta_of(1.1, 0.9, 0.2)
+    eng = Engine("Matern32", x, y, m)
+    try:
+        eng.objective(1, theta, z, 15, want_grad=True)
+        if m <= 64:
+            mean, var = eng.predict(xs)
+            ref_mean, ref_var = osg.predict("Matern32", x, y[:, 1], z, 1.1, 0.9, 0.2, xs)
+            assert np.max(np.abs(mean - ref_mean)) <= 1e-8 * np.max(np.abs(ref_mean)) and np.max(np.abs(var - ref_var) / ref_var) <= 1e-8
+        else:
+            with pytest.raises(Exception, match="gprx_factorize"):
+                eng.predict(xs)
+            eng.objective(1, theta, z, 15, want_grad=False)
+            mean, var = eng.predict(xs)
+            ref_mean, ref_var = osg.predict("Matern32", x, y[:, 1], z, 1.1, 0.9, 0.2, xs)
+            assert np.max(np.abs(mean - ref_mean)) <= 1e-8 * np.max(np.abs(ref_mean)) and np.max(np.abs(var - ref_var) / ref_var) <= 1e-8
+    finally:
+        eng.close()

@@ -1,6 +1,9 @@
 #!/bin/bash
 # tile-band height of the C_LOWER decode (gemm_f64.h GPRX_BAND) under the cell -> XCD mapping: fits/s and FETCH/WRITE traffic of the main kernel
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 cp gpras_amd/libgprx.so /tmp/libgprx_keep.so
 for b in 2 4 8 16; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DGPRX_BAND=$b -o gpras_amd/libgprx.so gpras_amd/csrc/gprx.hip || exit 1

@@ -4,6 +4,9 @@
 # WRITE_SIZE 2 -- MI355X_MICROARCH.md, "rocprofv3 PMC slots"; round 3 asked for both in one pass and rocprofv3 aborted with error 38).
 #     bash tools/pmc_cell.sh [tag]        -> gpurun_out/<tag>_pmc_cell_kernel.json (+ kernel stats of an un-instrumented run)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 tag=${1:-r04}
 export GPRX_CELL_KERNEL=1
 P="python3 tools/batch_n1024.py 1024 512"

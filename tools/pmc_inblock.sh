@@ -1,6 +1,9 @@
 #!/bin/bash
 # PMC passes over the batched step (128 cells, N = 4096): where do the in-block kernels (rows, short-K updates, diagonal) spend their cycles?
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 out=gpurun_out/pmc_inblock
 rm -rf $out; mkdir -p $out
 i=0

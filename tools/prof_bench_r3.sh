@@ -3,6 +3,9 @@
 # Kernel stats first, then each PMC group in a pass of its own (no tracing together with --pmc).  On the GPU box:
 #     bash tools/prof_bench_r3.sh <tag> [pmc]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 tag=${1:-r03_bench}
 B="python3 bench.py --steps 10 --warmup 2 --no-extras --batched-only"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o b -- $B > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_prof.log || exit 1

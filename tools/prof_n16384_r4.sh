@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 4: rocprofv3 kernel stats of ONE N = 16384 factorisation under schedule variants (env knobs).  bash tools/prof_n16384_r4.sh <tag> [VAR=val ...]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done
 rm -rf gpurun_out/prof_$tag

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 4: rocprofv3 kernel stats of the predict at the three sizes of the target.  On the GPU box: bash tools/prof_predict_r4.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 for cfg in "1024 8" "4096 8" "16384 12"; do
   set -- $cfg
   tag=r04_predict_n$1

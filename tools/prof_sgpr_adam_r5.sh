@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5: rocprofv3 kernel stats of the resident Adam loop (16 modes and 1 mode).  bash tools/prof_sgpr_adam_r5.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
 export GPRX_NO_BUILD=1
 for c in 16 1; do
   tag=r05_sgpr_adam_${c}modes

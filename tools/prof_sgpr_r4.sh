@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 4: rocprofv3 kernel stats of the batched sparse loss + gradient (16 cells and 1 cell of N = 4096, M = 50, d = 10).  bash tools/prof_sgpr_r4.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+#  the library is built BEFORE any profiler line; under rocprofv3 a stale library is an error, not a fork + exec of hipcc
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
+export GPRX_NO_BUILD=1
 for c in 16 1; do
   tag=r04_sgpr_${c}cells
   rm -rf gpurun_out/prof_$tag

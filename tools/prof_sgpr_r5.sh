@@ -2,6 +2,7 @@
 # Round 5: the fused sparse evaluation -- timing against the launch sequence, then rocprofv3 kernel stats (16 cells and 1 cell of
 # N = 4096, M = 50, d = 10).  bash tools/prof_sgpr_r5.sh   (the library must be built: no build under the profiler)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
 export GPRX_NO_BUILD=1
 python3 tools/sgpr_fused_probe.py 16 1 50 > gpurun_out/r05_sgpr_probe.log 2>&1 || { cat gpurun_out/r05_sgpr_probe.log; exit 1; }
 cat gpurun_out/r05_sgpr_probe.log

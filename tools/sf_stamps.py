@@ -33,6 +33,7 @@ names = {0: ("prep", ["par/Z in", "Kuu", "chain", "L, L^-1 out"]),
          64: ("mid", ["slab sum + L^-1 in", "chain", "LB out, c, logdet", "trsv m", "5 products + W, GQ out"]),
          96: ("pass2", ["fragments", "-> tile 0", "stage", "r2", "g, h + P", "mfma WP + P^T m + sum", "WP store, G, w v h", "dZ loop", "tiles 1..3", "partials out"]),
          128: ("final", ["all"])}
+print("prep chain steps (clocks):", [int(w[9 + i] - w[8 + i]) for i in range(8)])
 real = {b: w[b + 31] for b in names}
 t0 = min(real.values())
 for base, (kname, phases) in names.items():
