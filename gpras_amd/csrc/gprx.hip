@@ -1275,15 +1275,7 @@ SfParams sgpr_fused_params(gprx_handle h, const SgprLayout& L, bool want_grad) {
 int sgpr_fused_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_grad) {
   hipStream_t st = h->stream;
   const SgprStage sg = sgpr_stage(h, count, L);
-  SfParams p = sgpr_fused_params(h, L, want_grad);
-  // (the Kuu workgroups of launch 4 are separate while the whole launch is resident at once: one 512-thread workgroup per CU)
-  static const int n_cus = [] {
-    int v = 256;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    return v;
-  }();
-  p.q_appended = (int64_t)count * (p.nchunks + 1) > n_cus ? 1 : 0;
+  const SfParams p = sgpr_fused_params(h, L, want_grad);
   const int iso = (h->ard || h->dist_form) ? 0 : 1;
   HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, h->spin + sg.par, h->spin + sg.z, h->cellpar.p));
   HIPCHK(h, sf_launch_pass1(st, h->kid, h->dist_form, p, count));
@@ -1662,9 +1654,6 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   HIPCHK(h, hipStreamSynchronize(st));
   SfParams p = sgpr_fused_params(h, L, true);
   p.active = ad.active;
-  int n_cus = 256;
-  hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, h->device);
-  p.q_appended = (int64_t)count * (p.nchunks + 1) > n_cus ? 1 : 0;
   const int iso = (h->ard || h->dist_form) ? 0 : 1;
   static const int check_every = [] {
     const char* e = getenv("GPRX_ADAM_CHECK_EVERY");

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void sf_final_kernel(SfParams p, double* __res
       double acc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) off[u] = SF_P2_HEAD + min(e0 + 256 * u + tid, nz - 1);
-      sf_sum_chunks_n<4>(P2, off, p.p2w, p.nchunks + 1, acc);
+      sf_sum_chunks_n<4>(P2, off, p.p2w, p.nchunks, acc);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = e0 + 256 * u + tid;

@@ -116,22 +116,7 @@ __device__ __forceinline__ void sf_reduce_sums(const SfParams& p, const double* 
     }
     sums[e] = v;
   }
-  if (tid >= 128 && tid < 128 + width) {  // through Kuu
-    const int e = tid - 128;
-    const double* Pq = P2 + (int64_t)p.nchunks * p.p2w;
-    double v = 0.0;
-    if (e == 0) {
-      v = Pq[0];
-    } else if (e >= 2) {
-      const int k = e - 2;
-      if (ISO) {
-        if (k == 0) v = -Pq[1] / ls[0];
-      } else {
-        v = -Pq[4 + k] / ls[k];
-      }
-    }
-    sums[width + e] = v;
-  }
+  if (tid >= 128 && tid < 128 + width) sums[width + (tid - 128)] = 0.0;  // (the Kuu terms are inside the chunks' blocks since the slicing of pass 2)
 }
 
 // ---- one step of the resident Adam loop for one cell ---------------------------------------------------------------------------
@@ -196,7 +181,7 @@ __device__ __forceinline__ void sf_adam_body(const SfParams& p, const SfAdam& ad
         ve[u] = train_z ? vel[nt + e] : 0.0;
         x[u] = A[p.oZ + e];
       }
-      if (train_z) sf_sum_chunks_n<4>(P2, off, p.p2w, p.nchunks + 1, acc);
+      if (train_z) sf_sum_chunks_n<4>(P2, off, p.p2w, p.nchunks, acc);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = e0 + 256 * u + tid;

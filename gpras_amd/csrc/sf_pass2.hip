@@ -10,10 +10,14 @@
 namespace gprx {
 
 // ---- launch 4: the contractions -------------------------------------------------------------------------------------------
-// Workgroup (chunk < nchunks, cell): the chunk's columns of Kuf.  Workgroup (nchunks, cell): Kuu with weights G_Q.
+// Workgroup (chunk, cell): the chunk's 256 columns of Kuf with weights G_P, then ITS SLICE of the Kuu part -- columns
+// [chunk qw, (chunk + 1) qw) of Kuu, qw = ceil(64 / nchunks), with weights G_Q: a workgroup of its own for Kuu was a seventeenth
+// workgroup per cell, i.e. a second round of the launch at 16 cells (73 against 54 us), and appended whole to one workgroup it made
+// that one a fifth longer than the rest (42 against 34 us); sliced it costs every workgroup ~1 us.  The slicing depends on the
+// problem's shape only, never on the batch: same bits alone and in a batch.
 // Partial block of a workgroup (p2w doubles): [0] sum w g, [1] sum w v h r2 (ISO), [2] sum (y - P^T m)^2, [4 + k] sum w v h ds_k^2,
-// [SF_P2_HEAD + i d + k] sum_j w v h ds_k  -- all UNSCALED by the lengthscales; the Kuu workgroup stores its dZ sums doubled
-// (G_Q is symmetric: both index positions of z_i contribute).
+// [SF_P2_HEAD + i d + k] sum_j w v h ds_k  -- all UNSCALED by the lengthscales, Kuf and Kuu contributions added; the Kuu terms enter
+// dZ doubled (G_Q is symmetric: both index positions of z_i contribute).
 // 512 threads = 8 waves (two per SIMD, see sf_pass1.hip).  Row-lane layout: lane = inducing point, wave w = columns 8 w .. 8 w + 7;
 // MFMA layout: wave w owns row block w >> 1 (16 rows) and the column blocks 2 (w & 1), 2 (w & 1) + 1 of W P.
 // Registers: what crosses the MFMA product per element is ONE value (v h; isotropic: also r2) -- sum w g is formed in the MFMA layout
@@ -43,15 +47,10 @@ __global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
   const double* zp = A + p.oZ;
   const double* yp = p.Y + (int64_t)unit * p.np;
   SF_STAMP(p, 96, 0)
-  // The Kuu part of a cell is a workgroup of its own (chunk index nchunks) while every workgroup of the launch finds a CU at once; beyond
-  // that (q_appended) the workgroup of the cell's last chunk takes it as a second part -- 16 cells x 17 workgroups on 256 CUs ran the
-  // seventeenth ones as a second round (73 against 54 us).  Either way the same code fills partial block nchunks: same values.
-  const int nparts = (p.q_appended && chunk == p.nchunks - 1) ? 2 : 1;
-  for (int part = 0; part < nparts; ++part) {
-  const bool isq = p.q_appended ? part == 1 : chunk == p.nchunks;
-  const double* colpts = isq ? zp : p.X;
-  const int ncolpts = isq ? p.m : p.n;
-  const int ntiles = isq ? 1 : min(SF_TILES, (p.np - chunk * SF_CHUNK) / NB);
+  constexpr bool isq = false;  // (the tile loop below only sees columns of Kuf; its Kuu branches are compiled out)
+  const double* colpts = p.X;
+  const int ncolpts = p.n;
+  const int ntiles = min(SF_TILES, (p.np - chunk * SF_CHUNK) / NB);
   double raw[NB * SF_DK / SF_NT];
   sf_stage_fetch<SF_NT>(colpts, isq ? 0 : chunk * SF_CHUNK, ncolpts, p.d, 0, raw, tid);  // the first tile's points, before anything else
   double fw[4][4];  // W as MFMA A-operand fragments: rows 16 wm + r, k = 16 ks + 4 g + j (Kuf workgroups)
@@ -247,22 +246,97 @@ __global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
     }
     if (t == 0) { SF_STAMP(p, 96, 7) }
   }
+  // ---- this workgroup's slice of the Kuu part: weights G_Q, both points inducing points (their staged coordinates are in sZ) ----
+  double sgq = 0.0;
+  {
+    const int qw = (NB + p.nchunks - 1) / p.nchunks;
+    const int qc0 = chunk * qw, qc1 = min(qc0 + qw, NB);
+    if (qc0 < NB) {  // (uniform over the workgroup)
+      const int cbase = qc0 + wave * SF_NC;          // this wave's first column of the slice
+      const int base = min(cbase, NB - SF_NC);       // (clamped for addressing: slots outside the slice are masked)
+      double r2[SF_NC], nb[SF_NC], na = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < SF_NC; ++jj) r2[jj] = nb[jj] = 0.0;
+      if constexpr (NKC == 1) {
+        sf_r2_chunk<FORM, SF_NC, 0>(sZ, sZ + base * SF_DKP, lane, 0, p.d, r2, na, nb);
+      } else {
+        for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
+          __syncthreads();
+          sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
+          __syncthreads();
+          sf_r2_chunk<FORM, SF_NC, 0>(sZ, sZ + base * SF_DKP, lane, 0, min(SF_DK, p.d - k0), r2, na, nb);
+        }
+      }
+      double whq[SF_NC];
+#pragma unroll
+      for (int jj = 0; jj < SF_NC; ++jj) {
+        const int col = base + jj;
+        const bool live = col >= cbase && col < qc1 && col < p.m && lane < p.m;
+        double rr = r2[jj];
+        if constexpr (FORM != 0) rr = expanded_r2(na, nb[jj], rr);
+        double gv, hv;
+        corr_gh<KID>(rr, gv, hv);
+        const double wq = live ? A[p.oGQ + lane * NB + min(col, NB - 1)] : 0.0;
+        sgq = __builtin_fma(wq, gv, sgq);
+        whq[jj] = live ? wq * variance * hv : 0.0;
+        if constexpr (ISO != 0) siso = __builtin_fma(whq[jj], rr, siso);
+      }
+      for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
+        if constexpr (NKC != 1) {
+          if (p.d > SF_DK) {
+            __syncthreads();
+            sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
+            __syncthreads();
+          }
+        }
+        const int dk = min(SF_DK, p.d - k0);
+#pragma unroll
+        for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
+          if (kcs == (NKC == 1 ? 0 : k0 / SF_DK)) {
+#pragma unroll
+            for (int kk = 0; kk < (NP > 0 ? 2 * NP : SF_DK); kk += 2) {
+              if (kk < dk) {
+                d2 zv, xv[SF_NC];
+                sf_load_pair<SF_NC>(sZ, sZ + base * SF_DKP, lane, 0, kk, zv, xv);
+#pragma unroll
+                for (int jj = 0; jj < SF_NC; ++jj) {
+                  const double d0 = zv.x - xv[jj].x, d1 = zv.y - xv[jj].y;
+                  const double t0 = whq[jj] * d0, t1 = whq[jj] * d1;
+                  // (G_Q is symmetric: z_i sits at both index positions -> the dZ terms count twice; the lengthscale sums run over all pairs already)
+                  dz[kcs * SF_DK + kk] = __builtin_fma(2.0, t0, dz[kcs * SF_DK + kk]);
+                  dz[kcs * SF_DK + kk + 1] = __builtin_fma(2.0, t1, dz[kcs * SF_DK + kk + 1]);
+                  if constexpr (ISO == 0) {
+                    lsk[kcs * SF_DK + kk] = __builtin_fma(t0, d0, lsk[kcs * SF_DK + kk]);
+                    lsk[kcs * SF_DK + kk + 1] = __builtin_fma(t1, d1, lsk[kcs * SF_DK + kk + 1]);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
   SF_STAMP(p, 96, 8)
   // ---- this workgroup's partial block ----
-  double* out = A + p.oP2 + (int64_t)(isq ? p.nchunks : chunk) * p.p2w;
+  double* out = A + p.oP2 + (int64_t)chunk * p.p2w;
   {
     // (Kuf workgroups: sg so far is sum (W P) o P + sum y (P^T m), i.e. s v times sum G_P g)
-    const double a = wave_sum_dpp(sg), b = wave_sum_dpp(siso), c = wave_sum_dpp(resid);
+    const double a = wave_sum_dpp(sg), b = wave_sum_dpp(siso), c = wave_sum_dpp(resid), dq = wave_sum_dpp(sgq);
     if (lane == 0) {
       sRed[wave][0] = a;
       sRed[wave][1] = b;
       sRed[wave][2] = c;
+      sRed[wave][3] = dq;
     }
   }
   __syncthreads();
   if (tid < 3) {
     double v = ((sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid])) + ((sRed[4][tid] + sRed[5][tid]) + (sRed[6][tid] + sRed[7][tid]));
-    if (tid == 0 && !isq) v = v * inv_s / variance;
+    if (tid == 0) {
+      const double q = ((sRed[0][3] + sRed[1][3]) + (sRed[2][3] + sRed[3][3])) + ((sRed[4][3] + sRed[5][3]) + (sRed[6][3] + sRed[7][3]));
+      v = v * inv_s / variance + q;  // sum G_P g (the accumulated sum is s v times it) + this slice's sum G_Q g
+    }
     out[tid] = v;
   }
   // dZ: the eight waves' sums of every (row, dimension), four waves at a time through the tile image
@@ -292,7 +366,7 @@ __global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15, k = kc * SF_DK + kk;
-      if (k < p.d) out[SF_P2_HEAD + i * p.d + k] = isq ? 2.0 * part[u] : part[u];
+      if (k < p.d) out[SF_P2_HEAD + i * p.d + k] = part[u];
     }
     if constexpr (ISO == 0) {
       // dK/dl_k: sum over the 64 rows (lanes) and the 8 waves
@@ -318,12 +392,11 @@ __global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
       }
     }
   }
-  }  // part
   SF_STAMP(p, 96, 9)
 }
 
 hipError_t SF_CAT(sf_launch_pass2_kid, SF_KID)(hipStream_t st, int form, int iso, const SfParams& p, int cells) {
-  const dim3 grid(p.nchunks + (p.q_appended ? 0 : 1), cells), block(SF_NT);
+  const dim3 grid(p.nchunks, cells), block(SF_NT);
   const int np = p.d <= 12 ? 6 : (p.d <= SF_DK ? 8 : 0);
 #define SF_P2(F_, I_)                                                                                \
   if (np == 6) hipLaunchKernelGGL((sf_pass2_kernel<SF_KID, F_, I_, 6>), grid, block, 0, st, p);      \

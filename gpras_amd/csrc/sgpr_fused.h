@@ -50,7 +50,6 @@ struct SfParams {
   int cellres_stride;  // doubles
   int want_grad;
   const int* active;   // device-resident optimiser: per cell 0 = this cell has stopped (every launch returns at once for it); null: all run
-  int q_appended;      // launch 4: the Kuu part runs in the workgroup of the cell's last chunk instead of a workgroup of its own
   unsigned long long* stamps;  // development aid: null, or SF_STAMP_WORDS words that workgroup (0, 0) fills with s_memtime at its phase boundaries
 };
 // Device-resident Adam (gpr.py:147-173 for every cell of a batch): the optimiser's state lives in device memory, a step is the five
