@@ -1268,6 +1268,7 @@ SfParams sgpr_fused_params(gprx_handle h, const SgprLayout& L, bool want_grad) {
   p.cellres = h->cellres.p;
   p.cellres_stride = CELL_RES;
   p.want_grad = want_grad ? 1 : 0;
+  p.store_factors = 1;
   p.stamps = h->sf_stamps;
   return p;
 }
@@ -1654,6 +1655,7 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   HIPCHK(h, hipStreamSynchronize(st));
   SfParams p = sgpr_fused_params(h, L, true);
   p.active = ad.active;
+  p.store_factors = 0;  // (nobody predicts from the cell blocks of a running optimisation)
   const int iso = (h->ard || h->dist_form) ? 0 : 1;
   static const int check_every = [] {
     const char* e = getenv("GPRX_ADAM_CHECK_EVERY");

@@ -52,6 +52,105 @@ __global__ __launch_bounds__(256) void sf_prep_kernel(SfParams p, const double* 
   sf_prep_compute<KID, FORM>(p, cell, A, sQ, sZ, sIn, sXb, sTab, sPar, tid);
 }
 
+// The five products of the gradient algebra for ONE wave (template: everything unrolls).  Tiles (rt << 4 | ct), up to four per wave:
+// R = LB^-1 L^-1 is lower triangular (tile (rt, ct): k blocks ct .. rt -- 20 blocks in all, 5 per wave); Sigma^-1 = R^T R, T1 = L^-T T2 and
+// Q^-1 = L^-T L^-1 are symmetric (lower tiles, k blocks rt .. 3 -- 5 per wave); T2 = B L^-1: wave w = row block w, k blocks ct .. 3.
+// Every wave passes the same three barriers.
+template <bool TA, int RT, int CT, int KB0, int KB1>
+__device__ __forceinline__ d4 sf_tile_mm(const double* __restrict__ sa, const double* __restrict__ sbm, int g, int r) {
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kb = KB0; kb < KB1; ++kb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kb * 16 + 4 * g + j;
+      const double av = TA ? sa[k * SM_LD + RT * 16 + r] : sa[(RT * 16 + r) * SM_LD + k];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, sbm[k * SM_LD + CT * 16 + r], acc, 0, 0, 0);
+    }
+  return acc;
+}
+template <int RT, int CT>
+__device__ __forceinline__ void sf_tile_store(const d4& acc, double* __restrict__ dst, int g, int r) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[(RT * 16 + g + 4 * q) * SM_LD + CT * 16 + r] = acc[q];
+}
+template <int WAVE>
+struct SfMidTiles {
+  // slot -> code (rt << 4 | ct), 0xff = none
+  static constexpr int r_tile(int sl) {
+    constexpr int t[4][4] = {{0x30, 0x00, 0xff, 0xff}, {0x31, 0x10, 0xff, 0xff}, {0x20, 0x21, 0xff, 0xff}, {0x32, 0x11, 0x22, 0x33}};
+    return t[WAVE][sl];
+  }
+  static constexpr int s_tile(int sl) {
+    constexpr int t[4][4] = {{0x00, 0x30, 0xff, 0xff}, {0x10, 0x20, 0xff, 0xff}, {0x11, 0x21, 0xff, 0xff}, {0x22, 0x31, 0x32, 0x33}};
+    return t[WAVE][sl];
+  }
+};
+template <int WAVE, int SL>
+__device__ __forceinline__ void sf_mid_r_slot(const double* __restrict__ sB, const double* __restrict__ sL, double* __restrict__ sC, int g, int r) {
+  constexpr int code = SfMidTiles<WAVE>::r_tile(SL);
+  if constexpr (code != 0xff) {
+    constexpr int rt = code >> 4, ct = code & 15;
+    sf_tile_store<rt, ct>(sf_tile_mm<false, rt, ct, ct, rt + 1>(sB, sL, g, r), sC, g, r);
+  }
+}
+template <int WAVE, int SL>
+__device__ __forceinline__ void sf_mid_s_slot(const double* __restrict__ sC, d4& accS, int g, int r) {
+  constexpr int code = SfMidTiles<WAVE>::s_tile(SL);
+  if constexpr (code != 0xff) accS = sf_tile_mm<true, (code >> 4), (code & 15), (code >> 4), 4>(sC, sC, g, r);
+}
+template <int WAVE, int SL>
+__device__ __forceinline__ void sf_mid_w_slot(const double* __restrict__ sL, const double* __restrict__ sC, const d4& accS, const double* __restrict__ sb,
+                                              double* __restrict__ Wout, double* __restrict__ GQout, int g, int r) {
+  constexpr int code = SfMidTiles<WAVE>::s_tile(SL);
+  if constexpr (code != 0xff) {
+    constexpr int rt = code >> 4, ct = code & 15;
+    const d4 accT = sf_tile_mm<true, rt, ct, rt, 4>(sL, sC, g, r);
+    const d4 accQ = sf_tile_mm<true, rt, ct, rt, 4>(sL, sL, g, r);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rt * 16 + g + 4 * q, col = ct * 16 + r;
+      double w, gq;
+      sgpr_combine(accQ[q], accS[q], accT[q], sb[row], sb[col], w, gq);
+      Wout[row * NB + col] = w;
+      GQout[row * NB + col] = gq;
+      if (rt != ct) {  // W and G_Q on both sides of the diagonal
+        Wout[col * NB + row] = w;
+        GQout[col * NB + row] = gq;
+      }
+    }
+  }
+}
+template <int WAVE>
+__device__ __forceinline__ void sf_mid_products(const double* __restrict__ sL, const double* __restrict__ sB, double* __restrict__ sC,
+                                                const double* __restrict__ sBf, const double* __restrict__ sb, double* __restrict__ Wout,
+                                                double* __restrict__ GQout, int g, int r) {
+  // R = LB^-1 L^-1 (lower) -> sC
+  sf_mid_r_slot<WAVE, 0>(sB, sL, sC, g, r);
+  sf_mid_r_slot<WAVE, 1>(sB, sL, sC, g, r);
+  sf_mid_r_slot<WAVE, 2>(sB, sL, sC, g, r);
+  sf_mid_r_slot<WAVE, 3>(sB, sL, sC, g, r);
+  __syncthreads();
+  // Sigma^-1 = R^T R on the lower tiles (R[k][i] is zero for k < i: k blocks rt .. 3)
+  d4 accS[4];
+  sf_mid_s_slot<WAVE, 0>(sC, accS[0], g, r);
+  sf_mid_s_slot<WAVE, 1>(sC, accS[1], g, r);
+  sf_mid_s_slot<WAVE, 2>(sC, accS[2], g, r);
+  sf_mid_s_slot<WAVE, 3>(sC, accS[3], g, r);
+  __syncthreads();
+  // T2 = B L^-1 (all sixteen tiles: wave w = row block w; k blocks ct .. 3) -> sC
+  sf_tile_store<WAVE, 0>(sf_tile_mm<false, WAVE, 0, 0, 4>(sBf, sL, g, r), sC, g, r);
+  sf_tile_store<WAVE, 1>(sf_tile_mm<false, WAVE, 1, 1, 4>(sBf, sL, g, r), sC, g, r);
+  sf_tile_store<WAVE, 2>(sf_tile_mm<false, WAVE, 2, 2, 4>(sBf, sL, g, r), sC, g, r);
+  sf_tile_store<WAVE, 3>(sf_tile_mm<false, WAVE, 3, 3, 4>(sBf, sL, g, r), sC, g, r);
+  __syncthreads();
+  // T1 = L^-T T2 and Q^-1 = L^-T L^-1 on the lower tiles, combined into W and G_Q
+  sf_mid_w_slot<WAVE, 0>(sL, sC, accS[0], sb, Wout, GQout, g, r);
+  sf_mid_w_slot<WAVE, 1>(sL, sC, accS[1], sb, Wout, GQout, g, r);
+  sf_mid_w_slot<WAVE, 2>(sL, sC, accS[2], sb, Wout, GQout, g, r);
+  sf_mid_w_slot<WAVE, 3>(sL, sC, accS[3], sb, Wout, GQout, g, r);
+}
+
 // ---- launch 3: one workgroup per cell ------------------------------------------------------------------------------------
 // red (8 doubles per cell): [0] sum log diag LB, [1] |c|^2, [2] tr(A A^T) = tr(S) / s, [3] |LB^-1|_F^2
 __global__ __launch_bounds__(256) void sf_mid_kernel(SfParams p) {
@@ -146,13 +245,14 @@ __global__ __launch_bounds__(256) void sf_mid_kernel(SfParams p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = 16 * wave + g + 4 * q, col = 16 * kt + r;
-      A[p.oLB + row * NB + col] = acc[0][kt][q];
+      if (p.store_factors) A[p.oLB + row * NB + col] = acc[0][kt][q];
       if (row == col) sdiag[row] = acc[0][kt][q];
       sB[col * SM_LD + row] = acc[1][kt][q];  // LB^-1 = (acc[1])^T
     }
   __syncthreads();
   // LB^-1 to memory (the predict path reads it), c = LB^-1 (u / s)
-  for (int e = tid; e < NB * NB; e += 256) A[p.oLBinv + e] = sB[(e >> 6) * SM_LD + (e & 63)];
+  if (p.store_factors)
+    for (int e = tid; e < NB * NB; e += 256) A[p.oLBinv + e] = sB[(e >> 6) * SM_LD + (e & 63)];
   {
     const int row = tid & 63, qq = tid >> 6;
     double sum = 0.0;
@@ -164,7 +264,7 @@ __global__ __launch_bounds__(256) void sf_mid_kernel(SfParams p) {
   if (tid < NB) {
     const double cv = ((part[tid] + part[NB + tid]) + part[2 * NB + tid]) + part[3 * NB + tid];
     sb[tid] = cv;
-    A[p.oLB + NB * NB + tid] = cv;  // row 64 of the LB block: c (sgpr_predict_batch's layout)
+    if (p.store_factors) A[p.oLB + NB * NB + tid] = cv;  // row 64 of the LB block: c (sgpr_predict_batch's layout)
   }
   __syncthreads();
   if (wave == 0) {
@@ -196,74 +296,13 @@ __global__ __launch_bounds__(256) void sf_mid_kernel(SfParams p) {
   trsv_t64(sL, sb, reinterpret_cast<double(*)[NB]>(part), tid);  // m = L^-T LB^-T c
   if (tid < NB) A[p.oM + tid] = sb[tid];
   SF_STAMP(p, 64, 4)
-  // one 16 x 16 tile of op(A) B over the k blocks [kb0, kb1): op(A)[i][k] = TA ? A[k][i] : A[i][k]
-  auto tile_mm = [&](auto ta, const double* __restrict__ sa, const double* __restrict__ sbm, int rt, int ct, int kb0, int kb1) {
-    constexpr bool TA = decltype(ta)::value;
-    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-    for (int kb = kb0; kb < kb1; ++kb) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = kb * 16 + 4 * g + j;
-        const double av = TA ? sa[k * SM_LD + rt * 16 + r] : sa[(rt * 16 + r) * SM_LD + k];
-        const double bv = sbm[k * SM_LD + ct * 16 + r];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-    }
-    return acc;
-  };
-  auto tile_store = [&](const d4& acc, double* __restrict__ dst, int rt, int ct) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[(rt * 16 + g + 4 * q) * SM_LD + ct * 16 + r] = acc[q];
-  };
-  using std::false_type;
-  using std::true_type;
-  // lower tiles (rt << 2 | ct), four slots per wave, 0xff = none.  R: k blocks ct .. rt (20 in all, 5 per wave); the symmetric results:
-  // k blocks rt .. 3 (20 in all, 5 per wave)
-  constexpr unsigned char kTilesR[4][4] = {{0x30, 0x00, 0xff, 0xff}, {0x31, 0x10, 0xff, 0xff}, {0x20, 0x21, 0xff, 0xff}, {0x32, 0x11, 0x22, 0x33}};
-  constexpr unsigned char kTilesS[4][4] = {{0x00, 0x30, 0xff, 0xff}, {0x10, 0x20, 0xff, 0xff}, {0x11, 0x21, 0xff, 0xff}, {0x22, 0x31, 0x32, 0x33}};
-  // R = LB^-1 L^-1 (lower) -> sC
-#pragma unroll
-  for (int sl = 0; sl < 4; ++sl) {
-    const int code = kTilesR[wave][sl];
-    if (code != 0xff) {
-      const int rt = code >> 4, ct = code & 15;
-      tile_store(tile_mm(false_type{}, sB, sL, rt, ct, ct, rt + 1), sC, rt, ct);
-    }
-  }
-  __syncthreads();
-  // Sigma^-1 = R^T R on the lower tiles (R[k][i] is zero for k < i: k blocks rt .. 3)
-  d4 accS[4], accT[4], accQ[4];
-#pragma unroll
-  for (int sl = 0; sl < 4; ++sl) {
-    const int code = kTilesS[wave][sl];
-    if (code != 0xff) accS[sl] = tile_mm(true_type{}, sC, sC, code >> 4, code & 15, code >> 4, 4);
-  }
-  __syncthreads();
-  // T2 = B L^-1 (all sixteen tiles: wave w = row block w; k blocks ct .. 3) -> sC
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) tile_store(tile_mm(false_type{}, sBf, sL, wave, ct, ct, 4), sC, wave, ct);
-  __syncthreads();
-  // T1 = L^-T T2 and Q^-1 = L^-T L^-1 on the lower tiles; W and G_Q written on both sides of the diagonal
-#pragma unroll
-  for (int sl = 0; sl < 4; ++sl) {
-    const int code = kTilesS[wave][sl];
-    if (code != 0xff) {
-      const int rt = code >> 4, ct = code & 15;
-      accT[sl] = tile_mm(true_type{}, sL, sC, rt, ct, rt, 4);
-      accQ[sl] = tile_mm(true_type{}, sL, sL, rt, ct, rt, 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = rt * 16 + g + 4 * q, col = ct * 16 + r;
-        double w, gq;
-        sgpr_combine(accQ[sl][q], accS[sl][q], accT[sl][q], sb[row], sb[col], w, gq);
-        A[p.oW + row * NB + col] = w;
-        A[p.oGQ + row * NB + col] = gq;
-        if (rt != ct) {
-          A[p.oW + col * NB + row] = w;
-          A[p.oGQ + col * NB + row] = gq;
-        }
-      }
-    }
+  // (each wave runs its own fully unrolled copy: tile indices and k ranges are compile-time constants there, so the compiler hoists the
+  // LDS reads and interleaves the MFMAs of independent tiles -- an accumulation chain on ONE tile issues only every ~150 clocks)
+  switch (wave) {
+    case 0: sf_mid_products<0>(sL, sB, sC, sBf, sb, A + p.oW, A + p.oGQ, g, r); break;
+    case 1: sf_mid_products<1>(sL, sB, sC, sBf, sb, A + p.oW, A + p.oGQ, g, r); break;
+    case 2: sf_mid_products<2>(sL, sB, sC, sBf, sb, A + p.oW, A + p.oGQ, g, r); break;
+    default: sf_mid_products<3>(sL, sB, sC, sBf, sb, A + p.oW, A + p.oGQ, g, r); break;
   }
   SF_STAMP(p, 64, 5)
 }

@@ -56,7 +56,9 @@ __device__ __forceinline__ void sf_prep_compute(const SfParams& p, int cell, dou
     if (k0 > 0) __syncthreads();
     sf_stage<FORM>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
     __syncthreads();
-    sf_r2_chunk<FORM>(sZ, sZ, lane, wave, min(SF_DK, p.d - k0), r2, na, nb);
+    // (all eight pairs of the chunk, unconditionally: dimensions beyond d are staged as zeros and add exact zeros, and the unguarded
+    // loop is the hand-pipelined one -- the guarded loop waits out every LDS read)
+    sf_r2_chunk<FORM, 16, 8>(sZ, sZ, lane, wave, SF_DK, r2, na, nb);
   }
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
@@ -86,7 +88,7 @@ __device__ __forceinline__ void sf_prep_compute(const SfParams& p, int cell, dou
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = 16 * wave + g + 4 * q, col = 16 * kt + r;
-      A[p.oL + row * NB + col] = acc[0][kt][q];
+      if (p.store_factors) A[p.oL + row * NB + col] = acc[0][kt][q];
       sQ[col * SF_LD + row] = acc[1][kt][q];
     }
   __syncthreads();

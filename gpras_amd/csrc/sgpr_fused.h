@@ -49,6 +49,7 @@ struct SfParams {
   double* cellres;     // per cell CELL_RES doubles; [2] carries the pivot status as an int
   int cellres_stride;  // doubles
   int want_grad;
+  int store_factors;   // 1: L, LB, LB^-1 and c go to the cell block as well (the predict path reads them); the resident optimiser needs none of them
   const int* active;   // device-resident optimiser: per cell 0 = this cell has stopped (every launch returns at once for it); null: all run
   unsigned long long* stamps;  // development aid: null, or SF_STAMP_WORDS words that workgroup (0, 0) fills with s_memtime at its phase boundaries
 };

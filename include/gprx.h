@@ -175,11 +175,16 @@ int gprx_last_cell_kernel(gprx_handle h, double* ms, double* flops, double* cell
  * (count, n_theta) and z block i (count, m, d).  Replaces the serial loop over
  * self.models at gpr.py:272-274.  losses: count values; grads: (count, n_theta + m*d) or NULL.
  * With count > 1 (and d <= 64) every stage runs once for all cells, the cell index in every launch's grid: exact models
- * -- kernel build, Cholesky, solves, L^-1, K^-1, the trace pass (as gprx_factorize_batch) --, and sparse models -- Kuf,
- * Kuu, both Cholesky factorisations, A, B (split-K), c, the M x M products of the gradient, both trace passes, dZ: the
- * ~20 launches of one evaluation (M <= 64; more for larger M) serve all cells.  The values are bit-identical to gprx_objective on each cell.  A cell
+ * -- kernel build, Cholesky, solves, L^-1, K^-1, the trace pass (as gprx_factorize_batch) --, and sparse models.
+ * Sparse models with M <= 64 inducing points (the reference's example configuration has 50) take FIVE launches per evaluation
+ * whatever the cell count (round 5, csrc/sgpr_fused.h: Kuu and its factor | Kuf tile by tile on MFMA against the register-resident
+ * L^-1, never stored | B, its factor and the M x M algebra of the gradient | the contractions with dk/dtheta and dk/dZ | sums in a
+ * fixed order); count == 1 takes them too, and so does gprx_objective: a model evaluated alone and inside a batch gives the
+ * same bits.  Larger M takes the general launch sequence (Kuf, Kuu, both Cholesky factorisations, A, B (split-K), c, the M x M
+ * products of the gradient, both trace passes, dZ: ~45 launches serve all cells), bit-identical to gprx_objective on each cell.
+ * The tuning key "sgpr_fused" = 0 sends M <= 64 through that sequence as well (equal to rounding, not bit for bit).  A cell
  * whose matrix is not positive definite gets NaN loss and gradient and the call returns GPRX_ENOTPD after finishing the
- * others. */
+ * others.  The single-model state of the handle is left unfactorised (gprx_predict needs a gprx_factorize / gprx_objective). */
 int gprx_objective_batch(gprx_handle h, int count, const int* units, const double* theta, const double* z, int mask,
                          double* losses, double* grads);
 
@@ -273,14 +278,23 @@ int gprx_predict_batch_dev(gprx_handle h, int count, const int* units, const dou
                            double* means_dev, double* vars_dev, int include_noise);
 
 /* The reference's Adam driver (gpr.py:147-173: tf.keras.optimizers.Adam() defaults, at most max_iter steps, early stop once the
- * relative improvement of the loss stayed <= 1e-5 for more than 50 consecutive steps) for `count` cells in lock step: every step
+ * relative improvement of the loss stayed <= 1e-5 for more than 50 consecutive steps) for `count` cells in lock step.
+ * Sparse models with M <= 64 (round 5): the loop is RESIDENT ON THE DEVICE -- variables, moments, best loss and patience counters
+ * live in device memory, a step is four launches (the last one forms loss and gradient, applies the update and the stop rule and
+ * opens the next step with Kuu of the new variables; softplus, its derivative and the LogNormal priors are evaluated inside the
+ * kernel), cells that have stopped return at once from every launch, and the host only reads the stop flags every 25 steps
+ * (GPRX_ADAM_CHECK_EVERY): nothing else crosses the host link between the call's first upload and its last download.
+ * GPRX_ADAM_HOST=1 selects the host-stepped loop below instead; both give the same variables bit for bit (the scalar tail of an
+ * evaluation and the update are ONE source for host and device, csrc/sgpr_asm.h, on exp / log written out in IEEE operations,
+ * csrc/px_math.h).  Other models: every step
  * is ONE batched evaluation (gprx_objective_batch) of the cells still running, the update happens here on the host side of the
  * library -- no per-step round trip through the caller's language.  theta (count, n_theta) and z (count, m, d; NULL for exact
  * models) are the optimiser's variables, updated in place (elements outside `mask` stay as they are); n_evals[i] receives the
  * number of evaluations cell i took part in; batches (optional) the number of batched evaluations.  The arithmetic per element
  * is that of the NumPy statement of the update (one rounding per operation, no contraction): the result equals
  * gpras_amd.optimizers._optimize_adam on each cell bit for bit.  A cell whose matrix stops being positive definite ends the
- * call with GPRX_ENOTPD (gpr.py: the exception leaves the optimiser); theta / z hold the state of that step. */
+ * call with GPRX_ENOTPD (gpr.py: the exception leaves the optimiser); theta / z hold the state of that step (resident loop: the
+ * failing cell is as it was before the failing evaluation, the others may be up to 24 steps further: the flags are read every 25). */
 int gprx_adam_batch(gprx_handle h, int count, const int* units, double* theta, double* z, int mask, int max_iter, int* n_evals, int* batches);
 
 /* ---- EOF (PCA) projection either side of the GP path: SURVEY.md section 8(f) row N1 ------------------- */
@@ -377,7 +391,11 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * "poison_workspace" (testing, 1: the L^-1 workspace of the gradient starts as NaN patterns instead of whatever it held -- the
  * gradient never depends on its old contents, and no longer zeroes it).
  * Every schedule gives the same factor up to rounding; fused and split panels are bit-identical.
- * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution. */
+ * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution.
+ * "sgpr_fused": 1 (default) sparse models with M <= 64 take the five-launch evaluation and the device-resident Adam loop, 0: the
+ * general launch sequence (gprx_objective_batch); a handle's cell blocks are rebuilt when its value changes.
+ * "wait_handover_us" (process-wide): microseconds of polling after which a wait hands over to hipStreamSynchronize (default
+ * 200 000; tests set 0 to force the hand-over). */
 int gprx_set_tuning(const char* key, int value);
 int gprx_set_handle_tuning(gprx_handle h, const char* key, int value);
 
