@@ -25,6 +25,164 @@ namespace gprx {
 constexpr int SF_NT = 512;
 constexpr int SF_NC = 8;  // columns per lane in the row-lane layout
 
+// The end of a pass-2 workgroup: its slice of the Kuu part (weights G_Q, both points inducing
+// points: their staged coordinates are in sZ), then the partial block.  sEx: LDS scratch of at least 4 * NB * SF_DK doubles that nobody
+// reads any more; sRed: [8][4].
+template <int KID, int FORM, int ISO, int NP>
+__device__ __forceinline__ void sf_pass2_tail(const SfParams& p, double* __restrict__ A, const double* __restrict__ zp, const double* __restrict__ ls,
+                                              double variance, double inv_s, int chunk, int tid, double* __restrict__ sZ, double* __restrict__ sEx,
+                                              double (*__restrict__ sRed)[4], double sg, double siso, double resid,
+                                              double (&dz)[NP > 0 ? 2 * NP : 4 * SF_DK], double (&lsk)[ISO ? 1 : (NP > 0 ? 2 * NP : 4 * SF_DK)]) {
+  constexpr int NKC = NP > 0 ? 1 : 0;
+  constexpr int DZN = NP > 0 ? 2 * NP : 4 * SF_DK;
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- this workgroup's slice of the Kuu part: weights G_Q, both points inducing points (their staged coordinates are in sZ) ----
+  double sgq = 0.0;
+  {
+    const int qw = (NB + p.nchunks - 1) / p.nchunks;
+    const int qc0 = chunk * qw, qc1 = min(qc0 + qw, NB);
+    if (qc0 < NB) {  // (uniform over the workgroup)
+      const int cbase = qc0 + wave * SF_NC;          // this wave's first column of the slice
+      const int base = min(cbase, NB - SF_NC);       // (clamped for addressing: slots outside the slice are masked)
+      double r2[SF_NC], nb[SF_NC], na = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < SF_NC; ++jj) r2[jj] = nb[jj] = 0.0;
+      if constexpr (NKC == 1) {
+        sf_r2_chunk<FORM, SF_NC, 0>(sZ, sZ + base * SF_DKP, lane, 0, p.d, r2, na, nb);
+      } else {
+        for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
+          __syncthreads();
+          sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
+          __syncthreads();
+          sf_r2_chunk<FORM, SF_NC, 0>(sZ, sZ + base * SF_DKP, lane, 0, min(SF_DK, p.d - k0), r2, na, nb);
+        }
+      }
+      double whq[SF_NC];
+#pragma unroll
+      for (int jj = 0; jj < SF_NC; ++jj) {
+        const int col = base + jj;
+        const bool live = col >= cbase && col < qc1 && col < p.m && lane < p.m;
+        double rr = r2[jj];
+        if constexpr (FORM != 0) rr = expanded_r2(na, nb[jj], rr);
+        double gv, hv;
+        corr_gh<KID>(rr, gv, hv);
+        const double wq = live ? A[p.oGQ + lane * NB + min(col, NB - 1)] : 0.0;
+        sgq = __builtin_fma(wq, gv, sgq);
+        whq[jj] = live ? wq * variance * hv : 0.0;
+        if constexpr (ISO != 0) siso = __builtin_fma(whq[jj], rr, siso);
+      }
+      for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
+        if constexpr (NKC != 1) {
+          if (p.d > SF_DK) {
+            __syncthreads();
+            sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
+            __syncthreads();
+          }
+        }
+        const int dk = min(SF_DK, p.d - k0);
+#pragma unroll
+        for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
+          if (kcs == (NKC == 1 ? 0 : k0 / SF_DK)) {
+#pragma unroll
+            for (int kk = 0; kk < (NP > 0 ? 2 * NP : SF_DK); kk += 2) {
+              if (kk < dk) {
+                d2 zv, xv[SF_NC];
+                sf_load_pair<SF_NC>(sZ, sZ + base * SF_DKP, lane, 0, kk, zv, xv);
+#pragma unroll
+                for (int jj = 0; jj < SF_NC; ++jj) {
+                  const double d0 = zv.x - xv[jj].x, d1 = zv.y - xv[jj].y;
+                  const double t0 = whq[jj] * d0, t1 = whq[jj] * d1;
+                  // (G_Q is symmetric: z_i sits at both index positions -> the dZ terms count twice; the lengthscale sums run over all pairs already)
+                  dz[kcs * SF_DK + kk] = __builtin_fma(2.0, t0, dz[kcs * SF_DK + kk]);
+                  dz[kcs * SF_DK + kk + 1] = __builtin_fma(2.0, t1, dz[kcs * SF_DK + kk + 1]);
+                  if constexpr (ISO == 0) {
+                    lsk[kcs * SF_DK + kk] = __builtin_fma(t0, d0, lsk[kcs * SF_DK + kk]);
+                    lsk[kcs * SF_DK + kk + 1] = __builtin_fma(t1, d1, lsk[kcs * SF_DK + kk + 1]);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- this workgroup's partial block ----
+  double* out = A + p.oP2 + (int64_t)chunk * p.p2w;
+  {
+    // (Kuf workgroups: sg so far is sum (W P) o P + sum y (P^T m), i.e. s v times sum G_P g)
+    const double a = wave_sum_dpp(sg), b = wave_sum_dpp(siso), c = wave_sum_dpp(resid), dq = wave_sum_dpp(sgq);
+    if (lane == 0) {
+      sRed[wave][0] = a;
+      sRed[wave][1] = b;
+      sRed[wave][2] = c;
+      sRed[wave][3] = dq;
+    }
+  }
+  __syncthreads();
+  if (tid < 3) {
+    double v = ((sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid])) + ((sRed[4][tid] + sRed[5][tid]) + (sRed[6][tid] + sRed[7][tid]));
+    if (tid == 0) {
+      const double q = ((sRed[0][3] + sRed[1][3]) + (sRed[2][3] + sRed[3][3])) + ((sRed[4][3] + sRed[5][3]) + (sRed[6][3] + sRed[7][3]));
+      v = v * inv_s / variance + q;  // sum G_P g (the accumulated sum is s v times it) + this slice's sum G_Q g
+    }
+    out[tid] = v;
+  }
+  // dZ: the eight waves' sums of every (row, dimension), four waves at a time through the tile image
+  for (int kc = 0; kc * SF_DK < p.d; ++kc) {
+    double part[2] = {0.0, 0.0};  // this thread's two (row, dimension) entries: e = tid, tid + 512
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((wave >> 2) == half) {
+#pragma unroll
+        for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
+          if (kcs == kc) {
+#pragma unroll
+            for (int kk = 0; kk < SF_DK; ++kk) sEx[((wave & 3) * NB + lane) * SF_DK + kk] = kcs * SF_DK + kk < DZN ? dz[(kcs * SF_DK + kk) % DZN] : 0.0;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15;
+        const double v = ((sEx[(0 * NB + i) * SF_DK + kk] + sEx[(1 * NB + i) * SF_DK + kk]) + sEx[(2 * NB + i) * SF_DK + kk]) + sEx[(3 * NB + i) * SF_DK + kk];
+        part[u] = half == 0 ? v : part[u] + v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15, k = kc * SF_DK + kk;
+      if (k < p.d) out[SF_P2_HEAD + i * p.d + k] = part[u];
+    }
+    if constexpr (ISO == 0) {
+      // dK/dl_k: sum over the 64 rows (lanes) and the 8 waves
+      __syncthreads();
+#pragma unroll
+      for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
+        if (kcs == kc) {
+#pragma unroll
+          for (int kk = 0; kk < SF_DK; ++kk) {
+            if (kcs * SF_DK + kk < DZN) {
+              const double a = wave_sum_dpp(lsk[(kcs * SF_DK + kk) % DZN]);
+              if (lane == 0) sEx[wave * SF_DK + kk] = a;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < SF_DK && kc * SF_DK + tid < p.d) {
+        double v = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += sEx[w8 * SF_DK + tid];
+        out[4 + kc * SF_DK + tid] = v;
+      }
+    }
+  }
+}
+
+
 template <int KID, int FORM, int ISO, int NP>
 __global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
   constexpr int NKC = NP > 0 ? 1 : 0;
@@ -246,152 +404,7 @@ __global__ __launch_bounds__(SF_NT) void sf_pass2_kernel(SfParams p) {
     }
     if (t == 0) { SF_STAMP(p, 96, 7) }
   }
-  // ---- this workgroup's slice of the Kuu part: weights G_Q, both points inducing points (their staged coordinates are in sZ) ----
-  double sgq = 0.0;
-  {
-    const int qw = (NB + p.nchunks - 1) / p.nchunks;
-    const int qc0 = chunk * qw, qc1 = min(qc0 + qw, NB);
-    if (qc0 < NB) {  // (uniform over the workgroup)
-      const int cbase = qc0 + wave * SF_NC;          // this wave's first column of the slice
-      const int base = min(cbase, NB - SF_NC);       // (clamped for addressing: slots outside the slice are masked)
-      double r2[SF_NC], nb[SF_NC], na = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < SF_NC; ++jj) r2[jj] = nb[jj] = 0.0;
-      if constexpr (NKC == 1) {
-        sf_r2_chunk<FORM, SF_NC, 0>(sZ, sZ + base * SF_DKP, lane, 0, p.d, r2, na, nb);
-      } else {
-        for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
-          __syncthreads();
-          sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
-          __syncthreads();
-          sf_r2_chunk<FORM, SF_NC, 0>(sZ, sZ + base * SF_DKP, lane, 0, min(SF_DK, p.d - k0), r2, na, nb);
-        }
-      }
-      double whq[SF_NC];
-#pragma unroll
-      for (int jj = 0; jj < SF_NC; ++jj) {
-        const int col = base + jj;
-        const bool live = col >= cbase && col < qc1 && col < p.m && lane < p.m;
-        double rr = r2[jj];
-        if constexpr (FORM != 0) rr = expanded_r2(na, nb[jj], rr);
-        double gv, hv;
-        corr_gh<KID>(rr, gv, hv);
-        const double wq = live ? A[p.oGQ + lane * NB + min(col, NB - 1)] : 0.0;
-        sgq = __builtin_fma(wq, gv, sgq);
-        whq[jj] = live ? wq * variance * hv : 0.0;
-        if constexpr (ISO != 0) siso = __builtin_fma(whq[jj], rr, siso);
-      }
-      for (int k0 = 0; k0 < p.d; k0 += SF_DK) {
-        if constexpr (NKC != 1) {
-          if (p.d > SF_DK) {
-            __syncthreads();
-            sf_stage<FORM, SF_NT>(zp, 0, p.m, p.d, k0, ls, sZ, tid);
-            __syncthreads();
-          }
-        }
-        const int dk = min(SF_DK, p.d - k0);
-#pragma unroll
-        for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
-          if (kcs == (NKC == 1 ? 0 : k0 / SF_DK)) {
-#pragma unroll
-            for (int kk = 0; kk < (NP > 0 ? 2 * NP : SF_DK); kk += 2) {
-              if (kk < dk) {
-                d2 zv, xv[SF_NC];
-                sf_load_pair<SF_NC>(sZ, sZ + base * SF_DKP, lane, 0, kk, zv, xv);
-#pragma unroll
-                for (int jj = 0; jj < SF_NC; ++jj) {
-                  const double d0 = zv.x - xv[jj].x, d1 = zv.y - xv[jj].y;
-                  const double t0 = whq[jj] * d0, t1 = whq[jj] * d1;
-                  // (G_Q is symmetric: z_i sits at both index positions -> the dZ terms count twice; the lengthscale sums run over all pairs already)
-                  dz[kcs * SF_DK + kk] = __builtin_fma(2.0, t0, dz[kcs * SF_DK + kk]);
-                  dz[kcs * SF_DK + kk + 1] = __builtin_fma(2.0, t1, dz[kcs * SF_DK + kk + 1]);
-                  if constexpr (ISO == 0) {
-                    lsk[kcs * SF_DK + kk] = __builtin_fma(t0, d0, lsk[kcs * SF_DK + kk]);
-                    lsk[kcs * SF_DK + kk + 1] = __builtin_fma(t1, d1, lsk[kcs * SF_DK + kk + 1]);
-                  }
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  SF_STAMP(p, 96, 8)
-  // ---- this workgroup's partial block ----
-  double* out = A + p.oP2 + (int64_t)chunk * p.p2w;
-  {
-    // (Kuf workgroups: sg so far is sum (W P) o P + sum y (P^T m), i.e. s v times sum G_P g)
-    const double a = wave_sum_dpp(sg), b = wave_sum_dpp(siso), c = wave_sum_dpp(resid), dq = wave_sum_dpp(sgq);
-    if (lane == 0) {
-      sRed[wave][0] = a;
-      sRed[wave][1] = b;
-      sRed[wave][2] = c;
-      sRed[wave][3] = dq;
-    }
-  }
-  __syncthreads();
-  if (tid < 3) {
-    double v = ((sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid])) + ((sRed[4][tid] + sRed[5][tid]) + (sRed[6][tid] + sRed[7][tid]));
-    if (tid == 0) {
-      const double q = ((sRed[0][3] + sRed[1][3]) + (sRed[2][3] + sRed[3][3])) + ((sRed[4][3] + sRed[5][3]) + (sRed[6][3] + sRed[7][3]));
-      v = v * inv_s / variance + q;  // sum G_P g (the accumulated sum is s v times it) + this slice's sum G_Q g
-    }
-    out[tid] = v;
-  }
-  // dZ: the eight waves' sums of every (row, dimension), four waves at a time through the tile image
-  double* sEx = sPA;  // [4 waves][64 rows][16]
-  for (int kc = 0; kc * SF_DK < p.d; ++kc) {
-    double part[2] = {0.0, 0.0};  // this thread's two (row, dimension) entries: e = tid, tid + 512
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();
-      if ((wave >> 2) == half) {
-#pragma unroll
-        for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
-          if (kcs == kc) {
-#pragma unroll
-            for (int kk = 0; kk < SF_DK; ++kk) sEx[((wave & 3) * NB + lane) * SF_DK + kk] = kcs * SF_DK + kk < DZN ? dz[(kcs * SF_DK + kk) % DZN] : 0.0;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15;
-        const double v = ((sEx[(0 * NB + i) * SF_DK + kk] + sEx[(1 * NB + i) * SF_DK + kk]) + sEx[(2 * NB + i) * SF_DK + kk]) + sEx[(3 * NB + i) * SF_DK + kk];
-        part[u] = half == 0 ? v : part[u] + v;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = tid + SF_NT * u, i = e >> 4, kk = e & 15, k = kc * SF_DK + kk;
-      if (k < p.d) out[SF_P2_HEAD + i * p.d + k] = part[u];
-    }
-    if constexpr (ISO == 0) {
-      // dK/dl_k: sum over the 64 rows (lanes) and the 8 waves
-      __syncthreads();
-#pragma unroll
-      for (int kcs = 0; kcs < (NKC == 1 ? 1 : 4); ++kcs) {
-        if (kcs == kc) {
-#pragma unroll
-          for (int kk = 0; kk < SF_DK; ++kk) {
-            if (kcs * SF_DK + kk < DZN) {
-              const double a = wave_sum_dpp(lsk[(kcs * SF_DK + kk) % DZN]);
-              if (lane == 0) sEx[wave * SF_DK + kk] = a;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (tid < SF_DK && kc * SF_DK + tid < p.d) {
-        double v = 0.0;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) v += sEx[w8 * SF_DK + tid];
-        out[4 + kc * SF_DK + tid] = v;
-      }
-    }
-  }
+  sf_pass2_tail<KID, FORM, ISO, NP>(p, A, zp, ls, variance, inv_s, chunk, tid, sZ, sPA, sRed, sg, siso, resid, dz, lsk);
   SF_STAMP(p, 96, 9)
 }
 
