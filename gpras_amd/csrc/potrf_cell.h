@@ -33,7 +33,7 @@ constexpr int CELL_NI = GPRX_CELL_NI;
 // acknowledged and its loads have returned: an explicit s_waitcnt vmcnt(0).  __syncthreads() does not promise that wait -- for a
 // workgroup-scope release the compiler may leave vmcnt alone on this target (the waves of a workgroup share one L1, whose in-order
 // handling is taken to be enough); it was seen without one behind the chain's inverse stores.  (That was NOT the cause of the round-4
-// wrong results at two workgroups per CU -- see store_inverse_block in potrf_dag.h -- but the hand-off should not rest on it.)
+// wrong results at two workgroups per CU -- see store_inverse_block in tile_ops.h -- but the hand-off should not rest on it.)
 __device__ __forceinline__ void cell_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // threadIdx.x behind an opaque move: everything a phase derives from it (lane offsets, swizzles, buffer offsets) is computed INSIDE the
