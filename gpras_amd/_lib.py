@@ -157,7 +157,8 @@ def as_f64(a) -> np.ndarray:
 
 
 def ptr(a: np.ndarray):
-    return a.ctypes.data_as(_vp)
+    # (the address as an int: `a.ctypes.data_as(c_void_p)` costs 2.2 us per array, this 1.0 -- five arrays per batched evaluation)
+    return a.ctypes.data
 
 
 class DeviceBuffer:

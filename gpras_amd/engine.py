@@ -147,9 +147,10 @@ class Engine:
             if zs.shape != (units.size, self.m, self.d):
                 raise ValueError(f"zs must be ({units.size}, {self.m}, {self.d})")
             zp = ptr(zs)
-        # (NaN, not uninitialised memory: a cell the library did not reach must never look like a valid evaluation)
+        # (NaN, not uninitialised memory: a cell the library did not reach must never look like a valid evaluation -- the losses are
+        # pre-filled; the gradient block, 64 KB at 16 cells of M = 50, is filled below for the cells without a finite loss only)
         losses = np.full(units.size, np.nan)
-        grads = np.full((units.size, self.n_theta + self.m * self.d), np.nan) if want_grad else None
+        grads = np.empty((units.size, self.n_theta + self.m * self.d)) if want_grad else None
         rc = self._lib.gprx_objective_batch(self._h, units.size, ptr(units), ptr(thetas), zp, mask, ptr(losses), ptr(grads) if want_grad else None)
         if rc == _lib.GPRX_ENOMEM and units.size > 1:
             # the batch does not fit in device memory: two half batches (values do not depend on the batch composition)
@@ -159,7 +160,10 @@ class Engine:
             return (np.concatenate([lo[0], hi[0]]), None if not want_grad else np.concatenate([lo[1], hi[1]]), np.concatenate([lo[2], hi[2]]))
         if rc not in (_lib.GPRX_OK, _lib.GPRX_ENOTPD):
             check(rc, self._h)
-        return losses, grads, np.isfinite(losses)
+        ok = np.isfinite(losses)
+        if want_grad and rc != _lib.GPRX_OK:
+            grads[~ok] = np.nan
+        return losses, grads, ok
 
     @_locked
     def adam_batch(self, units, thetas, mask: int, max_iter: int, zs=None):
