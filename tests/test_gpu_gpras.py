@@ -229,6 +229,41 @@ def test_sparse_predict_is_batched_and_equals_the_per_mode_loop():
     assert np.max(np.abs(mean - rmean)) <= 1e-8 * np.max(np.abs(rmean)) and np.max(np.abs(var - rvar) / rvar) <= 1e-8
 
 
+@pytest.mark.parametrize("frozen", [dict(Z=False), dict(variance=False, noise=False), dict(lengthscales=False, Z=False)])
+def test_resident_adam_with_frozen_parameters_equals_the_python_loop(frozen):
+    """The device-resident Adam loop of the sparse model (M <= 64: update, stop rule and the next step's Kuu in one launch) with parts of
+    the model frozen, as the reference's two-stage fit freezes them (gpr.py:111-145): same variables bit for bit as the packed Python
+    loop over host evaluations, frozen parameters untouched, 70 steps (the stop flags are read every 25)."""
+    from gpras_amd import optimizers
+
+    x, y = make_hydrograph_features(300, 4, n_outputs=4, config=1, unit=23)
+
+    def prepared():
+        g = GPRAS("RBF")
+        g._init_models(x, y, 20, "grid")
+        for m in g.models:
+            m.set_all_trainable(True)
+            m.set_trainable(**frozen)
+            m.n_evals = 0
+        return g
+
+    a, b = prepared(), prepared()
+    before = [(m.variance, np.array(m.lengthscales, copy=True), m.noise, np.array(m.Z, copy=True)) for m in a.models]
+    optimizers._optimize_adam_many(a.models, 70)  # library loop (resident on the device)
+    batch = optimizers._PackedBatch(b.models)
+    optimizers._adam_packed(batch, np.stack([m.get_vector() for m in b.models]), 70, None)  # Python loop, batched host evaluations
+    for ma, mb, (v0, l0, s0, z0) in zip(a.models, b.models, before):
+        assert ma.n_evals == mb.n_evals and ma.n_evals > 50
+        assert np.array_equal(ma.get_vector(), mb.get_vector())
+        assert np.array_equal(ma.Z, mb.Z) and ma.variance == mb.variance and ma.noise == mb.noise
+        if frozen.get("Z") is False:
+            assert np.array_equal(ma.Z, z0)
+        if frozen.get("variance") is False:
+            assert ma.variance == v0 and ma.noise == s0
+        if frozen.get("lengthscales") is False:
+            assert np.array_equal(np.asarray(ma.lengthscales), l0)
+
+
 @pytest.mark.parametrize("n_inducing", [None, 16])
 def test_adam_inside_the_library_equals_the_python_loops(n_inducing):
     """gprx_adam_batch (the lock-step Adam driver inside libgprx.so) against the packed Python loop and against the serial
