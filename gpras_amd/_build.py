@@ -18,6 +18,8 @@ CSRC = PKG_DIR / "csrc"
 OBJ_DIR = PKG_DIR / "csrc" / "_obj"
 LIB_PATH = PKG_DIR / "libgprx.so"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# development builds (tools/chain_stamps.sh: -DGPRX_CHAIN_STAMPS ...): extra defines for every unit, part of the staleness check
+FLAGS += os.environ.get("GPRX_EXTRA_FLAGS", "").split()
 # (object name, source, extra defines)
 UNITS = (
     [("gprx", "gprx.hip", []), ("sf_cell", "sf_cell.hip", []), ("sf_adam", "sf_adam.hip", [])]

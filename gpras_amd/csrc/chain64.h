@@ -26,7 +26,7 @@ struct ChainCtx {
 };
 
 #ifdef GPRX_CHAIN_STAMPS
-__device__ unsigned long long g_chain_stamps[16];
+static __device__ unsigned long long g_chain_stamps[16];  // (one copy per translation unit: gprx_chain_stamps reads gprx.hip's)
 #define CSTAMP(i) if constexpr (P == 3) { if (c.tid == 0) g_chain_stamps[i] = __builtin_amdgcn_s_memtime(); }
 #else
 #define CSTAMP(i)

@@ -2,7 +2,8 @@
 # cycle stamps (s_memtime) inside sub-panel step 3 of the tile-DAG chain (a -DGPRX_CHAIN_STAMPS build): where a sub-panel step spends its time
 cd $GRAFT_REPO_ROOT
 cp gpras_amd/libgprx.so /tmp/libgprx_keep.so
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DGPRX_CHAIN_STAMPS -o gpras_amd/libgprx.so gpras_amd/csrc/gprx.hip || exit 1
+export GPRX_EXTRA_FLAGS=-DGPRX_CHAIN_STAMPS   # (every unit is rebuilt with the flag: ~1 min on the box; the library is restored below)
+python3 -m gpras_amd._build --stale > /dev/null || exit 1
 python3 - <<'PY'
 import ctypes as C, sys
 import numpy as np

@@ -1,8 +1,8 @@
-"""Cycle stamps of panel workgroup 0 (build with -DGPRX_PANEL_STAMPS into tools/libgprx_stamps.so).
+"""Cycle stamps of panel workgroup 0 (a -DGPRX_PANEL_STAMPS build: tools/libgprx_stamps.so, or the library named by GPRX_STAMPS_LIB).
 argv[1] = rows below the 64 x 64 diagonal block (one panel launch of rows/64 + 1 workgroups)."""
-import ctypes as C, sys, numpy as np
+import ctypes as C, os, sys, numpy as np
 sys.path.insert(0, ".")
-lib = C.CDLL("tools/libgprx_stamps.so")
+lib = C.CDLL(os.environ.get("GPRX_STAMPS_LIB", "tools/libgprx_stamps.so"))
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 lda = 4096
 rng = np.random.default_rng(0)
