@@ -263,6 +263,47 @@ def test_sparse_batch_failed_cell_is_isolated_and_leaves_no_trace(lib):
         lib.gprx_destroy(h)
 
 
+def test_resident_adam_reports_a_cell_that_stops_being_positive_definite(lib):
+    """gprx_adam_batch on sparse models with M <= 64 runs resident on the device (gprx.hip sgpr_adam_resident); a cell whose Kuu is
+    numerically singular from the first step on ends the call with GPRX_ENOTPD at the first read of the stop flags, names the cell,
+    leaves the other cells' variables finite, and the handle serves a clean run afterwards (same result as a run that never failed)."""
+    import ctypes as C
+
+    from gpras_amd import _lib
+    from gpras_amd._lib import check, ptr
+    from oracle import kernels as okn
+
+    n, d, m, cells = 500, 3, 24, 3
+    x, y, _ = make_regression(n, d, n_outputs=3, n_test=0, config=14, unit=5)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, m, okn.KERNEL_IDS["RBF"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), 3), h)
+    try:
+        rng = np.random.default_rng(9)
+        units = np.arange(cells, dtype=np.int32)
+        good = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, 3)))
+        zs0 = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] for _ in range(cells)]))
+
+        def run(thetas):
+            th, zs = thetas.copy(), zs0.copy()
+            n_evals, batches = np.zeros(cells, dtype=np.int32), C.c_int()
+            rc = lib.gprx_adam_batch(h, cells, ptr(units), ptr(th), ptr(zs), 15, 30, ptr(n_evals), C.byref(batches))
+            return rc, th, zs, n_evals
+
+        rc, th_ref, zs_ref, ev_ref = run(good)
+        assert rc == _lib.GPRX_OK and (ev_ref == 30).all()
+        bad = good.copy()
+        bad[1] = [1e12, 1e6, 0.0]
+        rc, th, zs, ev = run(bad)
+        assert rc == _lib.GPRX_ENOTPD
+        assert b"cell 1" in lib.gprx_last_error(h)
+        assert np.isfinite(th[[0, 2]]).all() and np.isfinite(zs[[0, 2]]).all()
+        rc, th2, zs2, ev2 = run(good)
+        assert rc == _lib.GPRX_OK and np.array_equal(th2, th_ref) and np.array_equal(zs2, zs_ref) and np.array_equal(ev2, ev_ref)
+    finally:
+        lib.gprx_destroy(h)
+
+
 def test_batched_sparse_evaluations_from_two_threads_on_two_handles(lib):
     """Two host threads, each with its own handle (own stream, own captured graph), evaluate batches at the same time: the
     captures must not disturb each other (they did -- "operation failed due to a previous error during capture" -- until the
