@@ -85,6 +85,9 @@ struct gprx_ctx {
   double* adam_pin = nullptr;                             // pinned: stop flags of the cells + the error word, read every few steps
   size_t adam_pin_bytes = 0;
   unsigned long long* sf_stamps = nullptr;                // development aid (gprx_sf_stamps): phase stamps of the fused sparse kernels
+  static constexpr int SF_MAX_GROUPS = 2;
+  hipStream_t sf_streams[SF_MAX_GROUPS - 1] = {};          // extra streams of the resident Adam loop: large batches run as groups of cells (sf_group_plan)
+  hipEvent_t sf_evs[SF_MAX_GROUPS] = {};
   bool sparse_view = false;                               // the current single-model factorisation lives in cell block 0 of `sarena`
   // current factorisation
   bool factorized = false;
@@ -1273,6 +1276,41 @@ SfParams sgpr_fused_params(gprx_handle h, const SgprLayout& L, bool want_grad) {
   return p;
 }
 
+// The resident Adam loop on large batches: TWO groups of cells on two streams.  Two of the four launches of a step (mid, Adam + prep) are
+// one workgroup per cell around a 64 x 64 chain: with all cells in lock step the chip idles through them (16 of 256 CUs busy for half of a
+// 16-cell step), and a pass over more than 16 cells takes a second round of 256 workgroups.  Two groups that start one launch apart keep
+// that distance: one group's single-workgroup launches run beside the other's streamed passes.  Measured per lock-step step (N = 4096,
+// d = 10, M = 50): 17 cells 183 -> 128 us, 28 cells 187 -> 131, 36 cells 244 -> 205, 50 cells 303 -> 223; 32 cells 188 -> 187 (a pass workgroup fills its CU --
+// 512 threads x 256 registers -- and a group of 16 cells occupies all 256: the other group's single workgroups find no CU until the
+// round ends); three and more groups LOSE (24 cells as three groups 252 us, 32 as three 258, 50 as five 307: streams beyond the second
+// do not run beside the first two on this runtime).  Every cell's arithmetic is untouched: same bits (tools/sgpr_groups_probe.py).
+// From `sf_groups_from()` cells on ("sgpr_groups_from", 0: never).  Host-driven evaluations stay one group: the cross-stream edges cost a
+// single call more than the overlap returns (16 cells 154 -> 210 us per call, 50 cells 360 -> 343).
+int& sf_groups_from() {
+  static int v = [] {
+    const char* e = getenv("GPRX_SF_GROUPS_FROM");
+    return e ? atoi(e) : 17;
+  }();
+  return v;
+}
+int sf_group_count(gprx_handle, int count) { return (sf_groups_from() <= 0 || count < sf_groups_from()) ? 1 : 2; }
+int sf_group_streams(gprx_handle h, int ngroups) {
+  for (int g = 0; g + 1 < ngroups; ++g)
+    if (!h->sf_streams[g]) HIPCHK(h, hipStreamCreateWithFlags(&h->sf_streams[g], hipStreamNonBlocking));
+  for (int g = 0; g < ngroups; ++g)
+    if (!h->sf_evs[g]) HIPCHK(h, hipEventCreateWithFlags(&h->sf_evs[g], hipEventDisableTiming));
+  return GPRX_OK;
+}
+// the parameter block of the cells [cell0, ...) of a batch: every per-cell base pointer moved (the kernels index cells from 0)
+SfParams sf_params_from(SfParams p, int cell0) {
+  p.arena += (int64_t)cell0 * p.ss;
+  p.cpar += (int64_t)cell0 * CELL_PAR;
+  p.cellres += (int64_t)cell0 * p.cellres_stride;
+  if (p.active) p.active += cell0;
+  if (cell0 != 0) p.stamps = nullptr;
+  return p;
+}
+
 int sgpr_fused_enqueue(gprx_handle h, int count, const SgprLayout& L, bool want_grad) {
   hipStream_t st = h->stream;
   const SgprStage sg = sgpr_stage(h, count, L);
@@ -1599,9 +1637,9 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   const int64_t nz = h->m * h->d, gw = nt + nz;
   // ---- device state: doubles first, then ints ----
   const size_t n_dbl = (size_t)count * nt + 2 * (size_t)count * gw + 2 * (size_t)count + (size_t)max_iter + 1 + (size_t)h->n_units;
-  const size_t n_int = 5 * (size_t)count + 1;
+  const size_t n_int = 5 * (size_t)count + gprx_ctx::SF_MAX_GROUPS;  // (one error word per group of cells)
   if ((rc = ensure(h, h->adam_dev, sizeof(double) * n_dbl + sizeof(int) * n_int))) return rc;
-  const size_t pin_need = sizeof(int) * ((size_t)count + 1);
+  const size_t pin_need = sizeof(int) * ((size_t)count + gprx_ctx::SF_MAX_GROUPS);
   if (h->adam_pin_bytes < pin_need) {
     if (h->adam_pin) HIPCHK(h, hipHostFree(h->adam_pin));
     h->adam_pin = nullptr;
@@ -1666,20 +1704,62 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   int error_cell = 0;
   h->factorized = false;  // the cell blocks are overwritten
   h->sparse_view = false;
-  HIPCHK(h, sf_launch_prep(st, h->kid, h->dist_form, p, count, nullptr, nullptr, h->cellpar.p, &ad));  // opens step 1
+  // (large batches: two groups of cells on two streams, one launch apart -- sf_group_count)
+  constexpr int MAXG = gprx_ctx::SF_MAX_GROUPS;
+  const int ngroups = sf_group_count(h, count);
+  if (ngroups > 1 && (rc = sf_group_streams(h, ngroups))) return rc;
+  SfParams pg[MAXG];
+  SfAdam adg[MAXG];
+  int cells_g[MAXG], cell0_g[MAXG];
+  hipStream_t sg_[MAXG];
+  for (int g = 0, cell0 = 0; g < ngroups; ++g) {
+    const int cells = count / ngroups + (g < count % ngroups ? 1 : 0);
+    sg_[g] = g == 0 ? st : h->sf_streams[g - 1];
+    cell0_g[g] = cell0;
+    cells_g[g] = cells;
+    pg[g] = sf_params_from(p, cell0);
+    adg[g] = ad;
+    adg[g].theta += (int64_t)cell0 * nt;
+    adg[g].mom += (int64_t)cell0 * gw;
+    adg[g].vel += (int64_t)cell0 * gw;
+    adg[g].best += cell0;
+    adg[g].loss += cell0;
+    adg[g].stale += cell0;
+    adg[g].active += cell0;
+    adg[g].n_evals += cell0;
+    adg[g].tstep += cell0;
+    adg[g].units += cell0;
+    adg[g].error += g;
+    cell0 += cells;
+  }
+  for (int g = 0; g < ngroups; ++g)
+    HIPCHK(h, sf_launch_prep(sg_[g], h->kid, h->dist_form, pg[g], cells_g[g], nullptr, nullptr, h->cellpar.p + (size_t)cell0_g[g] * CELL_PAR, &adg[g]));  // opens step 1
   for (int done = 0; done < max_iter;) {
     const int k = std::min(check_every, max_iter - done);
     for (int i = 0; i < k; ++i) {
-      HIPCHK(h, sf_launch_pass1(st, h->kid, h->dist_form, p, count));
-      HIPCHK(h, sf_launch_mid(st, p, count));
-      HIPCHK(h, sf_launch_pass2(st, h->kid, h->dist_form, iso, p, count));
-      HIPCHK(h, sf_launch_adam_prep(st, h->kid, h->dist_form, iso, p, count, ad, h->cellpar.p));  // closes this step, opens the next
+      for (int g = 0; g < ngroups; ++g) {
+        // (a group starts one launch behind the group before it; groups that start together stay in lock step and gain nothing)
+        const bool first = done == 0 && i == 0;
+        if (first && g > 0) HIPCHK(h, hipStreamWaitEvent(sg_[g], h->sf_evs[g - 1], 0));
+        HIPCHK(h, sf_launch_pass1(sg_[g], h->kid, h->dist_form, pg[g], cells_g[g]));
+        if (first && g + 1 < ngroups) HIPCHK(h, hipEventRecord(h->sf_evs[g], sg_[g]));
+        HIPCHK(h, sf_launch_mid(sg_[g], pg[g], cells_g[g]));
+        HIPCHK(h, sf_launch_pass2(sg_[g], h->kid, h->dist_form, iso, pg[g], cells_g[g]));
+        // closes this step, opens the next
+        HIPCHK(h, sf_launch_adam_prep(sg_[g], h->kid, h->dist_form, iso, pg[g], cells_g[g], adg[g], h->cellpar.p + (size_t)cell0_g[g] * CELL_PAR));
+      }
     }
     done += k;
+    for (int g = 1; g < ngroups; ++g) {
+      HIPCHK(h, hipEventRecord(h->sf_evs[g], sg_[g]));
+      HIPCHK(h, hipStreamWaitEvent(st, h->sf_evs[g], 0));
+    }
     HIPCHK(h, hipMemcpyAsync(flags, ad.active, sizeof(int) * count, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(flags + count, ad.error, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(flags + count, ad.error, sizeof(int) * ngroups, hipMemcpyDeviceToHost, st));
     HIPCHK(h, wait_stream(h, st));
-    error_cell = flags[count];
+    error_cell = 0;
+    for (int g = ngroups - 1; g >= 0; --g)
+      if (flags[count + g] != 0) error_cell = cell0_g[g] + flags[count + g];
     bool any = false;
     for (int c = 0; c < count; ++c) any = any || flags[c] != 0;
     if (error_cell != 0 || !any) break;
@@ -1785,6 +1865,10 @@ int gprx_destroy(gprx_handle h) {
   if (h->bpin) hipHostFree(h->bpin);
   if (h->spin) hipHostFree(h->spin);
   if (h->sf_stamps) hipFree(h->sf_stamps);
+  for (auto& ev : h->sf_evs)
+    if (ev) hipEventDestroy(ev);
+  for (auto& sx : h->sf_streams)
+    if (sx) hipStreamDestroy(sx);
   if (h->adam_dev.p) hipFree(h->adam_dev.p);
   if (h->adam_pin) hipHostFree(h->adam_pin);
   for (auto& ev : h->bev)
@@ -3337,6 +3421,7 @@ bool apply_tuning(PotrfTuning& t, int& predict_path, int& fused, const std::stri
   else if (k == "predict_path" && value >= 0 && value <= 2) predict_path = value;
   else if (k == "sgpr_fused" && value >= 0 && value <= 1) fused = value;
   else if (k == "wait_handover_us" && value >= 0) wait_handover_us() = value;  // (process-wide whichever entry point sets it)
+  else if (k == "sgpr_groups_from" && value >= 0) sf_groups_from() = value;    // (process-wide; 0: the resident Adam loop never splits a batch into groups)
   else return false;
   return true;
 }

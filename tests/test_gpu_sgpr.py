@@ -304,6 +304,51 @@ def test_resident_adam_reports_a_cell_that_stops_being_positive_definite(lib):
         lib.gprx_destroy(h)
 
 
+def test_resident_adam_in_two_groups_of_cells_equals_one_group(lib):
+    """From 17 cells on the resident Adam loop runs the batch as two groups of cells on two streams, one launch apart (gprx.hip
+    sf_group_count: one group's one-workgroup-per-cell launches beside the other's streamed passes).  Same variables and evaluation
+    counts bit for bit as with the grouping switched off ("sgpr_groups_from" = 0); a cell of the SECOND group that is not positive
+    definite is named by its index in the batch."""
+    import ctypes as C
+
+    from gpras_amd import _lib
+    from gpras_amd._lib import check, ptr
+    from oracle import kernels as okn
+
+    n, d, m, cells, outs = 400, 3, 20, 19, 4
+    x, y, _ = make_regression(n, d, n_outputs=outs, n_test=0, config=14, unit=19)
+    h = C.c_void_p()
+    check(lib.gprx_create(0, n, d, m, okn.KERNEL_IDS["Matern32"], 0, C.byref(h)))
+    check(lib.gprx_set_data(h, ptr(x), ptr(y), outs), h)
+    try:
+        rng = np.random.default_rng(19)
+        units = np.ascontiguousarray(rng.integers(0, outs, size=cells), dtype=np.int32)
+        th0 = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, 3)))
+        zs0 = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] for _ in range(cells)]))
+
+        def run(thetas, groups_from):
+            check(lib.gprx_set_tuning(b"sgpr_groups_from", groups_from))
+            th, zs = thetas.copy(), zs0.copy()
+            n_evals, batches = np.zeros(cells, dtype=np.int32), C.c_int()
+            rc = lib.gprx_adam_batch(h, cells, ptr(units), ptr(th), ptr(zs), 15, 40, ptr(n_evals), C.byref(batches))
+            return rc, th, zs, n_evals
+
+        rc1, th1, zs1, ev1 = run(th0, 0)
+        rc2, th2, zs2, ev2 = run(th0, 17)
+        assert rc1 == rc2 == _lib.GPRX_OK
+        assert np.array_equal(th1, th2) and np.array_equal(zs1, zs2) and np.array_equal(ev1, ev2) and (ev1 == 40).all()
+        assert not np.array_equal(th1, th0)
+        bad = th0.copy()
+        bad[15] = [1e12, 1e6, 0.0]  # (second group: cells 10 .. 18)
+        rc, th, zs, ev = run(bad, 17)
+        assert rc == _lib.GPRX_ENOTPD and b"cell 15" in lib.gprx_last_error(h)
+        rc3, th3, zs3, ev3 = run(th0, 17)
+        assert rc3 == _lib.GPRX_OK and np.array_equal(th3, th1) and np.array_equal(zs3, zs1)
+    finally:
+        lib.gprx_set_tuning(b"sgpr_groups_from", 17)
+        lib.gprx_destroy(h)
+
+
 def test_batched_sparse_evaluations_from_two_threads_on_two_handles(lib):
     """Two host threads, each with its own handle (own stream, own captured graph), evaluate batches at the same time: the
     captures must not disturb each other (they did -- "operation failed due to a previous error during capture" -- until the
