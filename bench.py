@@ -211,6 +211,17 @@ def sparse_section(device, extra):
     sp["adam_5000_steps_16_modes_M50"] = {"seconds": ta_, "evaluations_per_mode_min_max": [min(ev_), max(ev_)], "evaluations_per_s": sum(ev_) / ta_,
                                           "microseconds_per_lockstep_step": 1e6 * ta_ / max(ev_)}
     del g_
+    # more modes than 16 (the sweep goes to 50): from 17 cells on the resident loop runs two groups of cells on two streams, one launch apart
+    # (gprx.hip sf_group_count); 1 000 steps each
+    for modes in (28, 50):
+        g_ = GPRAS("RBF", device=device)
+        t1 = time.perf_counter()
+        g_.fit(xs50, ys50[:, :modes], 50, "kmeans", "adam", max_iter=1000)
+        ta_ = time.perf_counter() - t1
+        ev_ = [int(mm.n_evals) for mm in g_.models]
+        sp[f"adam_1000_steps_{modes}_modes_M50"] = {"seconds": ta_, "evaluations_per_mode_min_max": [min(ev_), max(ev_)], "evaluations_per_s": sum(ev_) / ta_,
+                                                   "microseconds_per_lockstep_step": 1e6 * ta_ / max(ev_)}
+        del g_
     # the same for M = 128 (host-stepped loop over the general launch sequence), 200 steps
     g_ = GPRAS("RBF", device=device)
     t1 = time.perf_counter()
