@@ -1098,6 +1098,8 @@ def main():
             "sgpr_batched16_loss_grad_evals_per_s": ex.get("sgpr_batched16_loss_grad_evals_per_s"),
             "sgpr_one_model_loss_grad_evals_per_s": ex.get("sgpr_n4096_d10_m50_loss_grad_evals_per_s"),
             "sgpr_16_modes_two_stage_fit_seconds": ex.get("sgpr_16_modes_two_stage_fit_seconds_lockstep"),
+            "sgpr_resident_adam_evals_per_s_16_28_50_modes": [((ex.get("sparse_sgpr") or {}).get(k) or {}).get("evaluations_per_s") for k in
+                                                              ("adam_5000_steps_16_modes_M50", "adam_1000_steps_28_modes_M50", "adam_1000_steps_50_modes_M50")],
             "cpu_baseline_fits_per_s": (result.get("cpu_baseline") or {}).get("value"),
         }
         print(json.dumps(ordered), flush=True)
