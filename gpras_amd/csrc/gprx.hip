@@ -1293,7 +1293,7 @@ int& sf_groups_from() {
   }();
   return v;
 }
-int sf_group_count(gprx_handle, int count) { return (sf_groups_from() <= 0 || count < sf_groups_from()) ? 1 : 2; }
+int sf_group_count(int count) { return (sf_groups_from() <= 0 || count < sf_groups_from()) ? 1 : 2; }
 int sf_group_streams(gprx_handle h, int ngroups) {
   for (int g = 0; g + 1 < ngroups; ++g)
     if (!h->sf_streams[g]) HIPCHK(h, hipStreamCreateWithFlags(&h->sf_streams[g], hipStreamNonBlocking));
@@ -1706,7 +1706,7 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   h->sparse_view = false;
   // (large batches: two groups of cells on two streams, one launch apart -- sf_group_count)
   constexpr int MAXG = gprx_ctx::SF_MAX_GROUPS;
-  const int ngroups = sf_group_count(h, count);
+  const int ngroups = sf_group_count(count);
   if (ngroups > 1 && (rc = sf_group_streams(h, ngroups))) return rc;
   SfParams pg[MAXG];
   SfAdam adg[MAXG];
@@ -1765,6 +1765,10 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
     if (error_cell != 0 || !any) break;
   }
   // ---- results ----
+  for (int g = 1; g < ngroups; ++g) {  // (nothing of the other group's stream may outlive the call: max_iter = 0 enqueued its prep launch only)
+    HIPCHK(h, hipEventRecord(h->sf_evs[g], sg_[g]));
+    HIPCHK(h, hipStreamWaitEvent(st, h->sf_evs[g], 0));
+  }
   HIPCHK(h, hipMemcpyAsync(theta, ad.theta, sizeof(double) * (size_t)count * nt, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpy2DAsync(z, sizeof(double) * (size_t)nz, h->sarena.p + L.oZ, sizeof(double) * (size_t)L.ss, sizeof(double) * (size_t)nz, count,
                              hipMemcpyDeviceToHost, st));

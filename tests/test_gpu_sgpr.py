@@ -326,13 +326,15 @@ def test_resident_adam_in_two_groups_of_cells_equals_one_group(lib):
         th0 = np.ascontiguousarray(rng.normal(0.2, 0.3, size=(cells, 3)))
         zs0 = np.ascontiguousarray(np.stack([x[rng.choice(n, size=m, replace=False)] for _ in range(cells)]))
 
-        def run(thetas, groups_from):
+        def run(thetas, groups_from, steps=40):
             check(lib.gprx_set_tuning(b"sgpr_groups_from", groups_from))
             th, zs = thetas.copy(), zs0.copy()
             n_evals, batches = np.zeros(cells, dtype=np.int32), C.c_int()
-            rc = lib.gprx_adam_batch(h, cells, ptr(units), ptr(th), ptr(zs), 15, 40, ptr(n_evals), C.byref(batches))
+            rc = lib.gprx_adam_batch(h, cells, ptr(units), ptr(th), ptr(zs), 15, steps, ptr(n_evals), C.byref(batches))
             return rc, th, zs, n_evals
 
+        rc0, th_0, zs_0, ev0 = run(th0, 17, steps=0)  # (no step: the variables come back as they went in, nothing is left running)
+        assert rc0 == _lib.GPRX_OK and np.array_equal(th_0, th0) and np.array_equal(zs_0, zs0) and (ev0 == 0).all()
         rc1, th1, zs1, ev1 = run(th0, 0)
         rc2, th2, zs2, ev2 = run(th0, 17)
         assert rc1 == rc2 == _lib.GPRX_OK
