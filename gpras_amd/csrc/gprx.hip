@@ -1284,7 +1284,7 @@ SfParams sgpr_fused_params(gprx_handle h, const SgprLayout& L, bool want_grad) {
 // 512 threads x 256 registers -- and a group of 16 cells occupies all 256: the other group's single workgroups find no CU until the
 // round ends); three and more groups LOSE (24 cells as three groups 252 us, 32 as three 258, 50 as five 307: streams beyond the second
 // do not run beside the first two on this runtime).  Every cell's arithmetic is untouched: same bits (tools/sgpr_groups_probe.py).
-// From `sf_groups_from()` cells on ("sgpr_groups_from", 0: never).  Host-driven evaluations stay one group: the cross-stream edges cost a
+// From `sf_groups_from()` cells on at 16 chunks per cell ("sgpr_groups_from", 0: never; sf_group_count).  Host-driven evaluations stay one group: the cross-stream edges cost a
 // single call more than the overlap returns (16 cells 154 -> 210 us per call, 50 cells 360 -> 343).
 int& sf_groups_from() {
   static int v = [] {
@@ -1293,7 +1293,12 @@ int& sf_groups_from() {
   }();
   return v;
 }
-int sf_group_count(int count) { return (sf_groups_from() <= 0 || count < sf_groups_from()) ? 1 : 2; }
+// (the threshold is stated in cells at N = 4096, i.e. 16 chunks of 256 columns per cell; what counts is whether a pass -- cells x chunks
+// workgroups -- needs more than one round of the 256 CUs: N = 8192 splits from 9 cells on, N = 2048 from 33)
+int sf_group_count(int count, int nchunks) {
+  if (sf_groups_from() <= 0 || count < 2) return 1;
+  return (int64_t)count * nchunks > (int64_t)(sf_groups_from() - 1) * 16 ? 2 : 1;
+}
 int sf_group_streams(gprx_handle h, int ngroups) {
   for (int g = 0; g + 1 < ngroups; ++g)
     if (!h->sf_streams[g]) HIPCHK(h, hipStreamCreateWithFlags(&h->sf_streams[g], hipStreamNonBlocking));
@@ -1706,7 +1711,7 @@ int sgpr_adam_resident(gprx_handle h, int count, const int* units, double* theta
   h->sparse_view = false;
   // (large batches: two groups of cells on two streams, one launch apart -- sf_group_count)
   constexpr int MAXG = gprx_ctx::SF_MAX_GROUPS;
-  const int ngroups = sf_group_count(count);
+  const int ngroups = sf_group_count(count, L.nsplit);
   if (ngroups > 1 && (rc = sf_group_streams(h, ngroups))) return rc;
   SfParams pg[MAXG];
   SfAdam adg[MAXG];

@@ -394,9 +394,10 @@ int gprx_gather_rows(int device, const double* field_dev, int64_t rows, int64_t 
  * "predict_path": 0 choose (default), 1 always the triangular GEMM against L^-1, 2 always blocked forward substitution.
  * "sgpr_fused": 1 (default) sparse models with M <= 64 take the five-launch evaluation and the device-resident Adam loop, 0: the
  * general launch sequence (gprx_objective_batch); a handle's cell blocks are rebuilt when its value changes.
- * "sgpr_groups_from" (process-wide): the device-resident Adam loop runs a batch of at least this many cells as two groups of cells on
- * two streams, one launch apart, so that one group's one-workgroup-per-cell launches overlap the other's streamed passes (default 17;
- * 0: never; every cell's values are the same bits either way).
+ * "sgpr_groups_from" (process-wide): the device-resident Adam loop runs a batch of at least this many cells (stated at N = 4096, i.e.
+ * 16 chunks of 256 training points per cell: the criterion is cells x chunks > 16 (value - 1), a pass that needs a second round of the
+ * CUs) as two groups of cells on two streams, one launch apart, so that one group's one-workgroup-per-cell launches overlap the
+ * other's streamed passes (default 17; 1: always; 0: never; every cell's values are the same bits either way).
  * "wait_handover_us" (process-wide): microseconds of polling after which a wait hands over to hipStreamSynchronize (default
  * 200 000; tests set 0 to force the hand-over). */
 int gprx_set_tuning(const char* key, int value);

@@ -305,10 +305,11 @@ def test_resident_adam_reports_a_cell_that_stops_being_positive_definite(lib):
 
 
 def test_resident_adam_in_two_groups_of_cells_equals_one_group(lib):
-    """From 17 cells on the resident Adam loop runs the batch as two groups of cells on two streams, one launch apart (gprx.hip
-    sf_group_count: one group's one-workgroup-per-cell launches beside the other's streamed passes).  Same variables and evaluation
-    counts bit for bit as with the grouping switched off ("sgpr_groups_from" = 0); a cell of the SECOND group that is not positive
-    definite is named by its index in the batch."""
+    """When a pass over the batch needs more than one round of the chip's CUs (17 cells at N = 4096) the resident Adam loop runs the batch
+    as two groups of cells on two streams, one launch apart (gprx.hip sf_group_count: one group's one-workgroup-per-cell launches beside
+    the other's streamed passes).  Forced here on a small problem ("sgpr_groups_from" = 1: two groups whatever the size): same variables
+    and evaluation counts bit for bit as with the grouping switched off (0); a cell of the SECOND group that is not positive definite is
+    named by its index in the batch; a run of zero steps leaves nothing running."""
     import ctypes as C
 
     from gpras_amd import _lib
@@ -333,18 +334,18 @@ def test_resident_adam_in_two_groups_of_cells_equals_one_group(lib):
             rc = lib.gprx_adam_batch(h, cells, ptr(units), ptr(th), ptr(zs), 15, steps, ptr(n_evals), C.byref(batches))
             return rc, th, zs, n_evals
 
-        rc0, th_0, zs_0, ev0 = run(th0, 17, steps=0)  # (no step: the variables come back as they went in, nothing is left running)
+        rc0, th_0, zs_0, ev0 = run(th0, 1, steps=0)  # (no step: the variables come back as they went in, nothing is left running)
         assert rc0 == _lib.GPRX_OK and np.array_equal(th_0, th0) and np.array_equal(zs_0, zs0) and (ev0 == 0).all()
         rc1, th1, zs1, ev1 = run(th0, 0)
-        rc2, th2, zs2, ev2 = run(th0, 17)
+        rc2, th2, zs2, ev2 = run(th0, 1)
         assert rc1 == rc2 == _lib.GPRX_OK
         assert np.array_equal(th1, th2) and np.array_equal(zs1, zs2) and np.array_equal(ev1, ev2) and (ev1 == 40).all()
         assert not np.array_equal(th1, th0)
         bad = th0.copy()
         bad[15] = [1e12, 1e6, 0.0]  # (second group: cells 10 .. 18)
-        rc, th, zs, ev = run(bad, 17)
+        rc, th, zs, ev = run(bad, 1)
         assert rc == _lib.GPRX_ENOTPD and b"cell 15" in lib.gprx_last_error(h)
-        rc3, th3, zs3, ev3 = run(th0, 17)
+        rc3, th3, zs3, ev3 = run(th0, 1)
         assert rc3 == _lib.GPRX_OK and np.array_equal(th3, th1) and np.array_equal(zs3, zs1)
     finally:
         lib.gprx_set_tuning(b"sgpr_groups_from", 17)

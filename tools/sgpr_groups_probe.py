@@ -9,7 +9,8 @@ from gpras_amd.gpr import GPRAS
 from gpras_amd.synth import make_regression
 
 lib = _lib.load()
-n, d, m = 4096, 10, 50
+import os
+n, d, m = int(os.environ.get("PROBE_N", "4096")), 10, 50
 for cells in [int(a) for a in sys.argv[1:]] or [16, 24, 32, 50]:
     x, y, _ = make_regression(n, d, n_outputs=cells, n_test=0, config=6, unit=1)
     ref = None
@@ -38,7 +39,7 @@ for cells in [int(a) for a in sys.argv[1:]] or [16, 24, 32, 50]:
             ref = (out[0].copy(), out[1].copy(), th.copy(), zz.copy())
         else:
             same = f"  same bits as one group: {np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1]) and np.array_equal(th, ref[2]) and np.array_equal(zz, ref[3])}"
-        print(f"cells={cells} groups={'yes' if groups_from else 'no'}: {dt*1e6:.1f} us per call = {cells/dt:.0f} evaluations/s; Adam {ta/steps*1e6:.1f} us per step "
+        print(f"N={n} cells={cells} groups={'yes' if groups_from else 'no'}: {dt*1e6:.1f} us per call = {cells/dt:.0f} evaluations/s; Adam {ta/steps*1e6:.1f} us per step "
               f"({int(ev.min())}-{int(ev.max())} evaluations per cell){same}", flush=True)
         del g
 check(lib.gprx_set_tuning(b"sgpr_groups_from", 17))
