@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, c
   for (int ii = 0; ii < DZ_IG; ++ii)
 #pragma unroll
     for (int kk = 0; kk < DZ_DC; ++kk) {
-      const double a = wave_sum(acc[ii][kk] + 2.0 * accq[ii][kk]);
+      const double a = wave_sum_dpp(acc[ii][kk] + 2.0 * accq[ii][kk]);  // (32 sums per workgroup: by ds_bpermute they were most of its time)
       if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][ii * DZ_DC + kk] = a;
     }
   __syncthreads();

@@ -149,27 +149,6 @@ __device__ __forceinline__ void sf_r2_chunk(const double* __restrict__ sRow, con
   }
 }
 
-// Sum over the 64 lanes of a wave by DPP moves (row shifts inside the rows of 16 lanes, then the two row broadcasts): ~20 vector
-// instructions with no LDS traffic; gprx_common.h wave_sum is 12 ds_bpermute round trips (~700 clocks when nothing hides them).  The total
-// is formed in lane 63 and read back with v_readlane: every lane of the wave receives it.  Other order of additions than wave_sum.
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-  auto shifted = [](double x, auto ctrl, auto row_mask) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
-    return __hiloint2double(hi, lo);
-  };
-  using std::integral_constant;
-  v += shifted(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
-  v += shifted(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
-  v += shifted(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
-  v += shifted(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8  -> lane 15 of every row: the row's sum
-  v += shifted(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
-  v += shifted(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3 -> lane 63: the total
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
-}
-
 // sum_c src[c * stride] for c = 0 .. count - 1, added in that order; the loads go out eight at a time (a rolled loop waits for every
 // load before it issues the next: 17 dependent round trips to memory another CU wrote cost ~14 us in the first version of sf_final)
 __device__ __forceinline__ double sf_sum_chunks(const double* __restrict__ src, int64_t stride, int count) {
