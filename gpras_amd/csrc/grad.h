@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256) void trace_pair_kernel(TraceArgs p, TraceArgs 
 // a row of WHP once per chunk of dimensions (one workgroup per (i, k) re-read x for every i and WHP for every k: 0.5 GB
 // of L2 traffic and 96 us for 16 cells of M = 50, N = 4096, d = 10).  Per output the operation order is unchanged:
 // thread t accumulates n = t, t + 256, ... with one FMA each, wave sums, the four waves added in order.
-constexpr int DZ_IG = 2, DZ_DC = 16;
+// Round 5: four inducing points per workgroup (X is re-read half as often), the Kuu terms in the same accumulators with doubled weights, wave sums
+// by DPP moves: 16 cells of M = 300, N = 4096, d = 10 157 -> 111 us, M = 128 56.6 -> 40.2 us.
+constexpr int DZ_IG = 4, DZ_DC = 16;
 __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, const double* __restrict__ X, const double* __restrict__ WHP,
                                                  int64_t ldp, const double* __restrict__ WHQ, int64_t ldq, const double* __restrict__ ls,
                                                  int m, int n, int d, double* __restrict__ dZ, int64_t cs = 0,
@@ -317,11 +319,11 @@ __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, c
   for (int ii = 0; ii < DZ_IG; ++ii)
 #pragma unroll
     for (int kk = 0; kk < DZ_DC; ++kk) z[ii][kk] = (ii < ni && kk < nk) ? Z[(int64_t)(i0 + ii) * d + k0 + kk] : 0.0;
-  double acc[DZ_IG][DZ_DC], accq[DZ_IG][DZ_DC];
+  double acc[DZ_IG][DZ_DC];  // (the Kuu terms enter the same sums with their weights doubled: G_Q is symmetric, z_i sits at both index positions)
 #pragma unroll
   for (int ii = 0; ii < DZ_IG; ++ii)
 #pragma unroll
-    for (int kk = 0; kk < DZ_DC; ++kk) acc[ii][kk] = accq[ii][kk] = 0.0;
+    for (int kk = 0; kk < DZ_DC; ++kk) acc[ii][kk] = 0.0;
   for (int c = threadIdx.x; c < n; c += 256) {
     double x[DZ_DC], w[DZ_IG];
 #pragma unroll
@@ -338,17 +340,17 @@ __global__ __launch_bounds__(256) void dz_kernel(const double* __restrict__ Z, c
 #pragma unroll
     for (int kk = 0; kk < DZ_DC; ++kk) x[kk] = kk < nk ? Z[(int64_t)c * d + k0 + kk] : 0.0;
 #pragma unroll
-    for (int ii = 0; ii < DZ_IG; ++ii) w[ii] = ii < ni ? WHQ[(int64_t)(i0 + ii) * ldq + c] : 0.0;
+    for (int ii = 0; ii < DZ_IG; ++ii) w[ii] = ii < ni ? 2.0 * WHQ[(int64_t)(i0 + ii) * ldq + c] : 0.0;
 #pragma unroll
     for (int ii = 0; ii < DZ_IG; ++ii)
 #pragma unroll
-      for (int kk = 0; kk < DZ_DC; ++kk) accq[ii][kk] = __builtin_fma(w[ii], z[ii][kk] - x[kk], accq[ii][kk]);
+      for (int kk = 0; kk < DZ_DC; ++kk) acc[ii][kk] = __builtin_fma(w[ii], z[ii][kk] - x[kk], acc[ii][kk]);
   }
 #pragma unroll
   for (int ii = 0; ii < DZ_IG; ++ii)
 #pragma unroll
     for (int kk = 0; kk < DZ_DC; ++kk) {
-      const double a = wave_sum_dpp(acc[ii][kk] + 2.0 * accq[ii][kk]);  // (32 sums per workgroup: by ds_bpermute they were most of its time)
+      const double a = wave_sum_dpp(acc[ii][kk]);  // (32 sums per workgroup: by ds_bpermute they were most of its time)
       if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][ii * DZ_DC + kk] = a;
     }
   __syncthreads();
