@@ -28,16 +28,19 @@ for _ in range(5):
 out = (C.c_ulonglong * 160)()
 check(lib.gprx_sf_stamps(eng._h, 1, out))
 w = np.array(list(out), dtype=np.uint64).astype(np.int64)
-names = {0: ("prep", ["par/Z in", "Kuu", "chain", "L, L^-1 out"]),
-         32: ("pass1", ["fragments", "-> tile 0", "stage", "r2", "exp + P", "mfma A'", "A' store", "mfma S + u", "tiles 1..3", "slab out"]),
-         64: ("mid", ["slab sum + L^-1 in", "chain", "LB out, c, logdet", "trsv m", "5 products + W, GQ out"]),
-         96: ("pass2", ["fragments", "-> tile 0", "stage", "r2", "g, h + P", "mfma WP + P^T m + sum", "WP store, G, w v h", "dZ loop", "tiles 1..3", "partials out"]),
-         128: ("final", ["all"])}
+# kernel -> (name, [(phase, first stamp, last stamp)]): the stamp indices of SF_STAMP in the kernels
+names = {0: ("prep", [("par / Z in", 0, 1), ("Kuu", 1, 2), ("chain", 2, 3), ("L, L^-1 out", 3, 4)]),
+         32: ("pass1", [("fragments, Z staged", 0, 1), ("tile 0 staged", 1, 2), ("r2", 2, 3), ("exp + P", 3, 4), ("mfma A'", 4, 5), ("A' store", 5, 6),
+                        ("mfma S + u", 6, 7), ("tiles 1..3", 7, 8), ("slab out", 8, 9)]),
+         64: ("mid", [("slab sum + L^-1 in", 0, 1), ("chain", 1, 2), ("LB out, c, logdet", 2, 3), ("trsv m", 3, 4), ("5 products + W, GQ out", 4, 5)]),
+         96: ("pass2", [("fragments", 0, 1), ("tile 0 staged", 1, 2), ("r2", 2, 3), ("g, h + P", 3, 4), ("mfma WP + P^T m + sum", 4, 5), ("WP store, G, w v h", 5, 6),
+                        ("dZ loop", 6, 7), ("tiles 1..3, Kuu slice, partials out", 7, 9)]),
+         128: ("final", [("all", 0, 1)])}
 print("prep chain steps (clocks):", [int(w[9 + i] - w[8 + i]) for i in range(8)])
 real = {b: w[b + 31] for b in names}
 t0 = min(real.values())
 for base, (kname, phases) in names.items():
-    s = w[base:base + len(phases) + 1]
-    print(f"{kname}: entry at +{(real[base] - t0) * 10} ns; total {int(s[len(phases)] - s[0])} clocks")
-    for i, ph in enumerate(phases):
-        print(f"    {ph:32s} {int(s[i + 1] - s[i]):8d}")
+    first, last = phases[0][1], phases[-1][2]
+    print(f"{kname}: entry at +{(real[base] - t0) * 10} ns; total {int(w[base + last] - w[base + first])} clocks")
+    for ph, a, b in phases:
+        print(f"    {ph:36s} {int(w[base + b] - w[base + a]):8d}")
