@@ -199,6 +199,17 @@ class GPRAS:
             variances.append(pred[1])
         return np.concatenate(means, axis=1), np.concatenate(variances, axis=1)
 
+    @staticmethod
+    def _scatter_rows(dst_mean, dst_var, part, mean, var):
+        """``(cells, N*)`` results of the modes ``part`` into the columns of the ``(N*, n_outputs)`` arrays: one transposed block copy when
+        the modes are consecutive (the usual case: 11 ms instead of 90 for 50 modes x 100 000 points), column by column otherwise."""
+        if part == list(range(part[0], part[0] + len(part))):
+            dst_mean[:, part[0] : part[0] + len(part)] = mean.T
+            dst_var[:, part[0] : part[0] + len(part)] = var.T
+        else:
+            for row, i in enumerate(part):
+                dst_mean[:, i], dst_var[:, i] = mean[row], var[row]
+
     def _predict_batched(self, x: NDArray[Any], indices: list[int] | None = None):
         """Exact models: the factorisations that ``predict_y`` recomputes per mode (gpr.py:337) are independent,
         so all modes of an engine are factorised by one batched launch sequence (``Engine.factorize_batch``) and
@@ -233,8 +244,7 @@ class GPRAS:
                         mean, var = eng.predict_batch(units, thetas, x)
                     except np.linalg.LinAlgError as exc:
                         raise RuntimeError(f"kernel matrix not positive definite for one of the modes {part}: {exc}") from exc
-                    for row, i in enumerate(part):
-                        means[:, i], variances[:, i] = mean[row], var[row]
+                    self._scatter_rows(means, variances, part, mean, var)
                     continue
                 _, ok = eng.factorize_batch(units, thetas, 0)
                 if not ok.all():
@@ -249,8 +259,9 @@ class GPRAS:
         """Sparse models (what the reference runs): all modes of an engine are factorised by one batched launch sequence and
         predicted by one batched predict (``gprx_predict_batch``: the ~30 small launches of a mode's factorise + predict_y serve
         every mode).  Same kernels and operation order per mode: the numbers equal the per-mode loop's bit for bit."""
-        means = np.full((x.shape[0], len(self.models)), np.nan)
-        variances = np.full((x.shape[0], len(self.models)), np.nan)
+        full = sorted(todo) == list(range(len(self.models)))  # (columns outside `todo` stay NaN)
+        means = np.empty((x.shape[0], len(self.models))) if full else np.full((x.shape[0], len(self.models)), np.nan)
+        variances = np.empty((x.shape[0], len(self.models))) if full else np.full((x.shape[0], len(self.models)), np.nan)
         by_engine: dict[int, list[int]] = {}
         for i in todo:
             by_engine.setdefault(id(self.models[i].backend), []).append(i)
@@ -263,8 +274,7 @@ class GPRAS:
                 thetas = np.stack([self.models[i].theta() for i in part])
                 zs = np.stack([self.models[i].Z for i in part])
                 mean, var = eng.predict_batch(units, thetas, x, zs=zs)
-                for row, i in enumerate(part):
-                    means[:, i], variances[:, i] = mean[row], var[row]
+                self._scatter_rows(means, variances, part, mean, var)
         return means, variances
 
     def to_file(self, json_path: str | Path, model_dir: str | Path | None = None) -> None:
