@@ -60,6 +60,7 @@ PROTOTYPES = {
     "gprx_last_profile": (C.c_int, [_vp, _dp]),
     "gprx_last_kernel_build": (C.c_int, [_vp, _dp, _dp]),
     "gprx_last_cell_kernel": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "gprx_predict_batch_t": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp, C.c_int]),
     "gprx_objective_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "gprx_adam_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "gprx_comm_runtime_check": (C.c_int, [C.c_int]),

@@ -2578,6 +2578,47 @@ int gprx_predict_batch(gprx_handle h, int count, const int* units, const double*
   return GPRX_OK;
 }
 
+int gprx_predict_batch_t(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
+                         double* means_t, double* vars_t, int include_noise) {
+  int rc;
+  if ((rc = check_handle(h))) return rc;
+  if (count <= 0 || !units || !thetas || ns < 0 || (ns > 0 && (!xs || !means_t || !vars_t))) return fail(h, GPRX_EINVAL, "null argument");
+  // as gprx_predict_batch, with every slab of cells transposed on the device before it leaves: the host block is written in its final
+  // (ns, count) layout -- whole when all cells fit one slab, by 2-D copies into the slab's columns otherwise
+  int slab = (int)std::max<int64_t>(1, std::min<int64_t>(count, ((int64_t)1 << 26) / std::max<int64_t>(2 * ns, 1)));
+  if (const char* e = getenv("GPRX_PREDICT_SLAB")) slab = std::max(1, std::min(count, atoi(e)));  // (tests: force the slab-by-slab copies)
+  if ((rc = ensure(h, h->xs, sizeof(double) * (ns * h->d + 4 * ns * slab + 16)))) return rc;
+  double* dxs = h->xs.p;
+  double* dmean = dxs + ns * h->d;
+  double* dvar = dmean + ns * slab;
+  double* tmean = dvar + ns * slab;
+  double* tvar = tmean + ns * slab;
+  if (ns > 0) HIPCHK(h, hipMemcpyAsync(dxs, xs, sizeof(double) * ns * h->d, hipMemcpyHostToDevice, h->stream));
+  for (int c0 = 0; c0 < count; c0 += slab) {
+    const int cnt = std::min(slab, count - c0);
+    if ((rc = predict_batch_core(h, cnt, units + c0, thetas + (int64_t)c0 * h->ntheta, z ? z + (int64_t)c0 * h->m * h->d : nullptr, dxs, ns, dmean, dvar,
+                                 include_noise)))
+      return rc;
+    if (ns > 0) {
+      const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)cnt * ns + 255) / 256, 4096);
+      hipLaunchKernelGGL(transpose_small_kernel, dim3(grid), dim3(256), 0, h->stream, (const double*)dmean, (int64_t)cnt, ns, tmean);
+      hipLaunchKernelGGL(transpose_small_kernel, dim3(grid), dim3(256), 0, h->stream, (const double*)dvar, (int64_t)cnt, ns, tvar);
+      HIPCHK(h, hipGetLastError());
+      if (cnt == count) {
+        HIPCHK(h, hipMemcpyAsync(means_t, tmean, sizeof(double) * ns * cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(vars_t, tvar, sizeof(double) * ns * cnt, hipMemcpyDeviceToHost, h->stream));
+      } else {
+        HIPCHK(h, hipMemcpy2DAsync(means_t + c0, sizeof(double) * count, tmean, sizeof(double) * cnt, sizeof(double) * cnt, (size_t)ns, hipMemcpyDeviceToHost,
+                                   h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(vars_t + c0, sizeof(double) * count, tvar, sizeof(double) * cnt, sizeof(double) * cnt, (size_t)ns, hipMemcpyDeviceToHost,
+                                   h->stream));
+      }
+    }
+    HIPCHK(h, wait_stream(h, h->stream));
+  }
+  return GPRX_OK;
+}
+
 // ---- EOF projection either side of the GP path ------------------------------
 namespace {
 int pfail(gprx_pca_handle p, int code, const std::string& msg) {

@@ -240,7 +240,12 @@ class GPRAS:
                 thetas = np.stack([self.models[i].theta() for i in part])
                 if hasattr(eng, "predict_batch"):
                     # one call: batched factorisations, L^-1 of every cell by batched launches, x uploaded once (gprx_predict_batch)
+                    consecutive = part == list(range(part[0], part[0] + len(part)))
                     try:
+                        if consecutive and hasattr(eng, "predict_batch_t"):
+                            mean_t, var_t = eng.predict_batch_t(units, thetas, x)
+                            means[:, part[0] : part[0] + len(part)], variances[:, part[0] : part[0] + len(part)] = mean_t, var_t
+                            continue
                         mean, var = eng.predict_batch(units, thetas, x)
                     except np.linalg.LinAlgError as exc:
                         raise RuntimeError(f"kernel matrix not positive definite for one of the modes {part}: {exc}") from exc
@@ -273,6 +278,13 @@ class GPRAS:
                 units = [self.models[i].unit for i in part]
                 thetas = np.stack([self.models[i].theta() for i in part])
                 zs = np.stack([self.models[i].Z for i in part])
+                consecutive = part == list(range(part[0], part[0] + len(part)))
+                if consecutive and hasattr(eng, "predict_batch_t"):
+                    mean_t, var_t = eng.predict_batch_t(units, thetas, x, zs=zs)  # (N*, modes of this part): already the layout returned
+                    if len(part) == len(self.models):
+                        return mean_t, var_t
+                    means[:, part[0] : part[0] + len(part)], variances[:, part[0] : part[0] + len(part)] = mean_t, var_t
+                    continue
                 mean, var = eng.predict_batch(units, thetas, x, zs=zs)
                 self._scatter_rows(means, variances, part, mean, var)
         return means, variances

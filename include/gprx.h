@@ -271,6 +271,11 @@ int gprx_potrf(int device, double* a_dev, int64_t lda, int64_t np, int64_t extra
 int gprx_predict_batch(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
                        double* means, double* vars, int include_noise);
 
+/* The same with the results in the layout GPRAS.predict returns (gpr.py:340-342: the modes' columns concatenated): means_t / vars_t
+ * (ns, count) row-major -- every slab of cells is transposed on the device before it is copied out.  Same values. */
+int gprx_predict_batch_t(gprx_handle h, int count, const int* units, const double* thetas, const double* z, const double* xs, int64_t ns,
+                         double* means_t, double* vars_t, int include_noise);
+
 /* The same with the test points and the results in DEVICE memory (means_dev / vars_dev: (count, ns) row-major), asynchronous
  * on the handle's stream once the batched factorisation has returned: predictions that stay in HBM for the reverse
  * projection and the metrics (production/analysis/pipeline.py:260-288). */

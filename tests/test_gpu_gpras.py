@@ -298,3 +298,26 @@ def test_adam_inside_the_library_equals_the_python_loops(n_inducing):
     for ma, mb, mc in zip(a.models, b.models, c.models):
         va, vb, vc = ma.get_vector(), mb.get_vector(), mc.get_vector()
         assert np.array_equal(va, vb) and np.array_equal(va, vc)
+
+
+@pytest.mark.parametrize("n_inducing", [None, 12])
+def test_predict_in_the_references_layout_equals_the_transposed_batched_predict(n_inducing, monkeypatch):
+    """gprx_predict_batch_t hands the predictions over as (N*, modes) -- the layout GPRAS.predict returns (gpr.py:340-342) --, transposed on
+    the device: the same bits as gprx_predict_batch's (modes, N*) block, whole and slab by slab (GPRX_PREDICT_SLAB forces the 2-D copies)."""
+    x, y = make_hydrograph_features(200, 3, n_outputs=5, config=1, unit=31)
+    xs = make_hydrograph_features(333, 3, n_outputs=1, config=1, unit=32)[0]
+    g = GPRAS("Matern32")
+    g.fit(x, y, n_inducing, "grid", "adam", max_iter=2)
+    eng = g.engine
+    units = np.arange(5, dtype=np.int32)
+    thetas = np.stack([m.theta() for m in g.models])
+    zs = None if n_inducing is None else np.stack([m.Z for m in g.models])
+    mean, var = eng.predict_batch(units, thetas, xs, zs=zs)
+    for slab in (None, "2"):
+        if slab:
+            monkeypatch.setenv("GPRX_PREDICT_SLAB", slab)
+        mean_t, var_t = eng.predict_batch_t(units, thetas, xs, zs=zs)
+        assert mean_t.shape == (333, 5) and np.array_equal(mean_t, mean.T) and np.array_equal(var_t, var.T)
+    monkeypatch.delenv("GPRX_PREDICT_SLAB")
+    pm, pv = g.predict(xs)
+    assert np.array_equal(pm, mean.T) and np.array_equal(pv, var.T)
