@@ -196,10 +196,15 @@ def sparse_section(device, extra):
     extra["sgpr_units_per_s_lockstep"] = 16 / sp["two_stage_fit_seconds_16_modes_M50"]
     # sparse predict (gpr.py:336-339): 50 fitted modes at N* = 100 000 points through GPRAS.predict (host arrays in, host arrays out)
     g_.predict(xt50[:4096])
-    t1 = time.perf_counter()
-    pm_, pv_ = g_.predict(xt50)
-    tp_ = time.perf_counter() - t1
-    sp["predict_50_modes_M50_n_test_100000"] = {"seconds_host_to_host": tp_, "points_per_s_all_modes": 50 * xt50.shape[0] / tp_, "finite": bool(np.all(np.isfinite(pm_)) and np.all(pv_ > 0))}
+    tp_, tp_first = np.inf, None
+    for _ in range(3):  # (the first call at this size also allocates the device staging: reported beside the best of three)
+        t1 = time.perf_counter()
+        pm_, pv_ = g_.predict(xt50)
+        dt_ = time.perf_counter() - t1
+        tp_first = dt_ if tp_first is None else tp_first
+        tp_ = min(tp_, dt_)
+    sp["predict_50_modes_M50_n_test_100000"] = {"seconds_host_to_host": tp_, "seconds_first_call": tp_first, "timing": "best of 3", "points_per_s_all_modes": 50 * xt50.shape[0] / tp_,
+                                                 "finite": bool(np.all(np.isfinite(pm_)) and np.all(pv_ > 0))}
     del g_
     # a long Adam run, the cross-validation's regime (max_iter 5 000 - 10 000 there): 5 000 steps on all variables, 16 modes, M = 50;
     # the early stop (patience 50 at 1e-5 relative improvement) may end modes sooner -- evaluations are reported
