@@ -187,7 +187,7 @@ class GPRAS:
 
     def predict(self, x: NDArray[Any]) -> tuple[NDArray[Any], NDArray[Any]]:
         """Predictive mean and observation variance, each (n_samples, n_outputs) (gpr.py:322-342)."""
-        x = x.astype(np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)  # (the reference's astype copy is not needed: x is neither kept nor written)
         batched = self._predict_batched(x)
         if batched is not None:
             return batched
